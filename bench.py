@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — reads/s classified (150 bp reads vs a 1024-leaf SBT) on N MI355X, one process per GPU.
+
+A "step" is one pass of the hot path (pfq_query_batch_device: k-mer hashing + Bloom frontier + leaf certificates)
+over one batch of synthetic 150 bp reads that is already resident in HBM.  Workload = BASELINE.json config 2/3
+(SURVEY.md §8d): balanced 1024-leaf SBT over 50 kbp random genomes, k=21, nbits=71 887 936, 10 hashes, fixed
+seeds; reads 50 % positive (uniform leaf / offset / strand, error-free) and 50 % uniform random, theta = 1.0.
+With N > 1 every rank holds a replica of the tree, classifies its own shard of the reads (weak scaling, no
+data-path collective) and the per-genome counts are combined by ONE RCCL all-reduce inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the dominant kernel
+(HIP-event time measured live on the launch stream) and `cpu_baseline` (the CPU oracle in reference-faithful
+mode on the host cores, rank 0, N = 1 only; a reported baseline, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+K, NBITS, NUM_HASHES = 21, 71887936, 10
+SEEDS = (0x0123456789ABCDEF, 0xFEDCBA9876543210)
+GENOME_SEED, READ_SEED = 0x5EED0000, 0x5EED1234
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--leaves", type=int, default=1024)
+    ap.add_argument("--reads-per-step", type=int, default=8 * 1024 * 1024, help="per GPU")
+    ap.add_argument("--genome-len", type=int, default=50000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--threshold", type=float, default=1.0)
+    ap.add_argument("--path", type=int, default=-1, help="-1 auto, 0 direct kernel, 1 bucketed")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables it")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    from phagefilter_amd import BloomTree, _ffi
+    L = _ffi.lib()
+    n_g, glen, rl, B = args.leaves, args.genome_len, args.read_len, args.reads_per_step
+    ids = [f"G{i:05d}" for i in range(n_g)]
+
+    # ---- database: genomes generated on the device, SBT built on the device (replica per GPU)
+    t_setup = time.perf_counter()
+    genomes = torch.empty(n_g * glen, dtype=torch.uint8, device=dev)
+    _ffi.check(L.pfq_synth_genomes_device(genomes.data_ptr(), n_g, glen, GENOME_SEED, None))
+    torch.cuda.synchronize()
+    tree = BloomTree.build_balanced_device(genomes.data_ptr(), glen, n_g, ids, K, NBITS, NUM_HASHES, SEEDS[0], SEEDS[1],
+                                           0.001, 5000000, device=local_rank)
+    tree.set_path(args.path)
+
+    # ---- reads: every (step, rank) gets its own slice of the global read index space, resident in HBM
+    n_batches = min(args.steps + args.warmup, 16)
+    reads = torch.empty(n_batches * B * rl + 64, dtype=torch.uint8, device=dev)
+    for b in range(n_batches):
+        first = (b * world + rank) * B
+        _ffi.check(L.pfq_synth_reads_device(reads.data_ptr() + b * B * rl, first, B, rl, genomes.data_ptr(), glen, n_g,
+                                            READ_SEED, None))
+    off = torch.arange(B + 1, dtype=torch.int64, device=dev) * rl
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i: int) -> None:
+        b = i % n_batches
+        tree.query_device(reads.data_ptr() + b * B * rl, off.data_ptr(), B, B * rl, args.threshold, stream)
+
+    step(0)  # builds the HBM layout on first use (not timed)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    tree.reset_counts()
+    counts = torch.zeros(n_g, dtype=torch.int64, device=dev)
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    # ---- timed region: exactly K steps + the single all-reduce of per-genome counts
+    tree.profile_begin(args.steps)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    tree.export_counts(counts.data_ptr(), stream)
+    if world > 1:
+        dist.all_reduce(counts)  # RCCL over xGMI: 8 KiB at 1024 leaves
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    prof = tree.profile_end()
+    st = tree.last_stats()
+    total_reads = world * args.steps * B
+    total_hits = int(counts.sum().item())
+
+    result = None
+    if rank == 0:
+        kern = {"k_classify": prof.classify_ms, "bucket(scan+scatter)": prof.bucket_ms, "k_verify": prof.verify_ms,
+                "k_finalize": prof.finalize_ms}
+        dom = max(kern, key=kern.get)
+        avg_ms = kern[dom] / max(prof.calls, 1)
+        read_bytes = B * rl
+        cert_bytes = int(st.algorithmic_bytes) - read_bytes
+        alg = cert_bytes if dom == "k_verify" else int(st.algorithmic_bytes)
+        achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("reads_per_step") == B and tj.get("leaves") == n_g and tj.get("kernel") == dom:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "reads/sec classified (150 bp, 1024-leaf SBT) at 1/2/4/8 MI355X; bit-exact vs CPU",
+            "value": total_reads / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{B} synthetic {rl} bp reads per step per GPU (50% positive / 50% random, theta={args.threshold}) "
+                                   f"vs balanced {n_g}-leaf SBT, k={K}, nbits={NBITS}, {NUM_HASHES} hashes",
+                       "reads_per_step_per_gpu": B, "read_len": rl, "leaves": n_g, "k": K, "nbits": NBITS,
+                       "num_hashes": NUM_HASHES, "threshold": args.threshold,
+                       "parallelism": f"reads sharded x{world}, tree replicated per GPU, one RCCL all-reduce of per-genome counts"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom, "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": alg},
+            "query_path": "bucketed(screen+L2-sliced verify)" if st.path == 1 else "direct",
+            "n_slices": int(st.n_slices),
+            "kernel_ms_per_step": {k: v / max(prof.calls, 1) for k, v in kern.items()},
+            "hits_total": total_hits, "hits_last_step": int(st.n_hits), "candidates_last_step": int(st.n_candidates),
+            "setup_seconds": setup_s,
+        }
+
+    # ---- CPU baseline: oracle in reference-faithful mode on the host cores (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        result["cpu_baseline"] = cpu_baseline(tree, reads, n_g, ids, B, rl, args, np, torch)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    tree.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(tree, reads, n_g, ids, B, rl, args, np, torch):
+    """Oracle (`oracle/`, kind "port": a C restatement of the reference CPU path — the reference is Rust and cannot
+    be built here) timed on a bounded prefix of step 0's reads, same tree (copied back from HBM), all host cores."""
+    from oracle import pfq_oracle as orc
+    cores = len(os.sched_getaffinity(0))
+    ot = orc.balanced_topology(ids, K, NBITS, NUM_HASHES, SEEDS[0], SEEDS[1], 0.001, 5000000, alloc_bits=False)
+    ot.bits = np.empty((ot.n_nodes, ot.n_words), dtype=np.uint64)
+    for v in range(ot.n_nodes):
+        ot.bits[v] = tree.node_filter(v)
+    chunk, done, secs, probes = 20000, 0, 0.0, 0
+    t_wall = time.perf_counter()
+    gpu_check = None
+    while done + chunk <= B and (time.perf_counter() - t_wall) < args.cpu_seconds:
+        seq = reads[done * rl:(done + chunk) * rl].cpu().numpy()
+        seq = np.concatenate([seq, np.zeros(16, dtype=np.uint8)])
+        off = np.arange(chunk + 1, dtype=np.uint64) * rl
+        before = list(ot.mapped_reads)
+        _, p, s = orc.query_batch_packed(ot, seq, off, args.threshold, faithful=True, threads=cores, want_hits=False)
+        if gpu_check is None:  # parity of the first chunk: GPU counts vs oracle counts on the same reads
+            tree.reset_counts()
+            tree.query_packed(seq, off, args.threshold)
+            want = [(ot.tax_id[v], ot.mapped_reads[v] - before[v]) for v in ot.leaves_dfs()]
+            gpu_check = "ok" if tree.get_leaf_counts() == want else "MISMATCH"
+        done += chunk
+        secs += s
+        probes += p
+        chunk = min(chunk * 2, 200000)
+    return {"value": done / secs if secs > 0 else 0.0, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"first {done} reads of step 0 (same tree copied back from HBM); oracle in reference-faithful mode "
+                      f"(DFS with per-node re-hash and per-k-mer early exit, query.rs:99-158), query phase only",
+            "probes_per_read": probes / max(done, 1), "gpu_parity_on_sample": gpu_check}
+
+
+if __name__ == "__main__":
+    main()

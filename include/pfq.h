@@ -1,0 +1,164 @@
+/*
+ * pfq.h — C ABI of libpfq: MI355X-native read classification against a PhageFilter Sequence Bloom Tree.
+ *
+ * This is the drop-in boundary for ONE path of Dreycey/PhageFilter: `phage_filter query`
+ * (src/main.rs:249-376 -> src/query.rs:66-158).  The reference has no FFI of its own; each entry point
+ * below replaces the in-process call a Rust `main.rs` makes at that seam and is what its FFI (`extern "C"`
+ * block) would bind.  Paths are relative to the reference repository root.
+ *
+ * Conventions: every function returns PFQ_OK (0) or a negative pfq_status; nothing unwinds across the
+ * boundary; `pfq_last_error()` gives the message of the last failure on the calling thread.  The caller owns
+ * every input buffer; outputs marked "library-owned" stay valid until the next call on the same tree.
+ * One calling thread per pfq_tree (the reference's block loop is serial, main.rs:334-368).
+ * There is NO CPU fallback: every entry point that computes needs a gfx950 device and fails with
+ * PFQ_ERR_DEVICE otherwise.
+ */
+#ifndef PFQ_H
+#define PFQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pfq_status {
+    PFQ_OK = 0,
+    PFQ_ERR_ARG = -1,         /* bad argument */
+    PFQ_ERR_IO = -2,          /* file missing / unreadable (reference: panic in bloom_tree.rs:375-379, bloom_filter.rs:155-168) */
+    PFQ_ERR_FORMAT = -3,      /* tree.bin / .bf does not parse or is inconsistent */
+    PFQ_ERR_UNSUPPORTED = -4, /* valid database outside the device path's limits */
+    PFQ_ERR_DEVICE = -5,      /* HIP error / no gfx950 device */
+    PFQ_ERR_STATE = -6        /* call order (e.g. query on an empty tree) */
+} pfq_status;
+
+typedef struct pfq_tree pfq_tree; /* BloomTree (bloom_tree.rs:29-48) + its filters, resident in HBM */
+
+/* Tree-wide parameters: BloomTree fields (bloom_tree.rs:39-47) + the per-filter constants every node shares
+ * (bloom_filter.rs:86-89; identical for all nodes because bloom_tree.rs:279-290 builds every filter alike). */
+typedef struct pfq_info {
+    uint64_t kmer_size;
+    uint64_t nbits;
+    uint32_t num_hashes;
+    uint32_t largest_expected_genome;
+    float false_pos_rate;
+    uint32_t superset_verified; /* 1: parent ⊇ child holds on every edge (checked on the device at load) */
+    uint64_t seed1, seed2;
+    uint64_t n_nodes, n_leaves, n_filters;
+    uint64_t device_bytes; /* HBM held by this tree */
+} pfq_info;
+
+/* Per-read results of one pfq_query_batch call: CSR read -> leaf indices (indices into pfq_leaf_counts'
+ * left-to-right leaf order).  Replaces ResultMap (result_map.rs:9-46) at the seam of query.rs:146-154. */
+typedef struct pfq_hits {
+    uint64_t n_reads;
+    const uint64_t *offsets; /* [n_reads + 1], library-owned */
+    const uint32_t *leaves;  /* [offsets[n_reads]], ascending within a read, library-owned */
+} pfq_hits;
+
+#define PFQ_WANT_HITS 1u /* fill pfq_hits (needed for POS/NEG filtering, main.rs:345-361) */
+
+/* ---- database ---- */
+
+/* BloomTree::load (bloom_tree.rs:364-386) + every BloomFilter::load_from_file the LRU cache would do lazily
+ * (cache.rs:56-77, bloom_filter.rs:153-174): parses <db_dir>/tree.bin and each node's .bf (filters are keyed
+ * by their relative path exactly like the cache), uploads them, verifies parent ⊇ child per edge and builds
+ * the device layout.  `device` = HIP device ordinal. */
+int pfq_tree_open(const char *db_dir, int device, pfq_tree **out);
+
+/* Synthetic balanced SBT built on the device: leaf i = all canonical k-mers of genome i
+ * (what bloom_tree.rs:154-168 inserts), internal = OR of children (bloom_tree.rs:238-239), complete-as-possible
+ * balanced shape, leaf tax_id = tax_ids[i], internal tax_id = "Internal_Node_<n>".  genomes/offsets are HOST
+ * buffers: genome i = genomes[offsets[i] .. offsets[i+1]).  NOT the reference's greedy `build`. */
+int pfq_tree_build_balanced(const uint8_t *genomes, const uint64_t *offsets, uint64_t n_genomes,
+                            const char *const *tax_ids, uint64_t kmer_size, uint64_t nbits, uint32_t num_hashes,
+                            uint64_t seed1, uint64_t seed2, float false_pos_rate, uint32_t largest_expected_genome,
+                            int device, pfq_tree **out);
+/* Same, with genomes already in device memory (n_genomes x genome_len bytes, contiguous). */
+int pfq_tree_build_balanced_device(const uint8_t *d_genomes, uint64_t genome_len, uint64_t n_genomes,
+                                   const char *const *tax_ids, uint64_t kmer_size, uint64_t nbits,
+                                   uint32_t num_hashes, uint64_t seed1, uint64_t seed2, float false_pos_rate,
+                                   uint32_t largest_expected_genome, int device, pfq_tree **out);
+
+/* BloomTree::save (bloom_tree.rs:339-355) + the .bf files BloomFilter::save_to_file writes
+ * (bloom_filter.rs:176-205), so the reference binary can open a tree built here. */
+int pfq_tree_save(const pfq_tree *tree, const char *db_dir);
+
+int pfq_tree_info(const pfq_tree *tree, pfq_info *out);
+
+/* BloomTree::prune_tree (bloom_tree.rs:302-330): nodes at depth >= search_depth become leaves. */
+int pfq_tree_prune(pfq_tree *tree, uint64_t search_depth);
+
+void pfq_tree_close(pfq_tree *tree);
+
+/* ---- query ---- */
+
+/* query::query_batch (query.rs:66-82) for one block of reads given as raw bytes: read i =
+ * seq[offsets[i] .. offsets[i+1]) (HOST buffers).  k-mer extraction (file_parser.rs:135-148) happens on the
+ * device.  Leaf counts accumulate across calls like BloomNode::mapped_reads (query.rs:143).  `hits` may be NULL
+ * unless PFQ_WANT_HITS is set. */
+int pfq_query_batch(pfq_tree *tree, const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads, float threshold,
+                    uint32_t flags, pfq_hits *hits);
+
+/* Same with the block already resident in HBM (device pointers) on HIP stream `stream` (hipStream_t, may be
+ * NULL for the default stream).  Asynchronous unless PFQ_WANT_HITS is set; counts are final after the stream
+ * is synchronised.  This is the entry the benchmark times. */
+int pfq_query_batch_device(pfq_tree *tree, const uint8_t *d_seq, const uint64_t *d_offsets, uint64_t n_reads,
+                           uint64_t total_bytes, float threshold, uint32_t flags, void *stream, pfq_hits *hits);
+
+/* get_leaf_counts (query.rs:197-218): leaves left-to-right, zeros included.  Library-owned arrays. */
+int pfq_leaf_counts(pfq_tree *tree, const char *const **tax_ids, const uint64_t **counts, uint64_t *n_leaves);
+/* save_leaf_counts (query.rs:173-183): "<tax_id>,<count>\n" for count > 0, no header. */
+int pfq_save_leaf_counts(pfq_tree *tree, const char *csv_path);
+
+/* Multi-GPU reduction hooks (one process per GPU; the host framework all-reduces with RCCL):
+ * copy the u64[n_leaves] device counters out to / in from a device buffer on `stream`. */
+int pfq_leaf_counts_export(pfq_tree *tree, uint64_t *d_dst, void *stream);
+int pfq_leaf_counts_import(pfq_tree *tree, const uint64_t *d_src, void *stream);
+int pfq_leaf_counts_reset(pfq_tree *tree);
+
+/* ---- measurement / test hooks ---- */
+
+/* Per-call statistics of the last pfq_query_batch[_device] (valid after the stream is synchronised). */
+typedef struct pfq_stats {
+    uint64_t n_reads, n_candidates, n_hits, n_allhit_reads;
+    uint64_t algorithmic_bytes; /* sum_r L(r) + |hits(r)| * need(r) * num_hashes * 32 */
+    uint32_t path;              /* 0 = direct kernel, 1 = bucketed (screen + L2-sliced verify) */
+    uint32_t n_slices;
+} pfq_stats;
+int pfq_last_stats(pfq_tree *tree, pfq_stats *out);
+/* Force a query path: -1 auto, 0 direct, 1 bucketed. */
+int pfq_set_path(pfq_tree *tree, int path);
+
+/* Per-kernel device time of the query path, measured with HIP events recorded on the stream the kernels are
+ * launched on.  begin: record around the kernels of the next (up to max_calls) query calls; end: synchronise and sum. */
+typedef struct pfq_profile {
+    uint64_t calls;
+    double classify_ms; /* k_classify (screen frontier + inline certificates) */
+    double bucket_ms;   /* bucket scan + scatter */
+    double verify_ms;   /* k_verify (L2-sliced certificates) */
+    double finalize_ms; /* k_finalize */
+} pfq_profile;
+int pfq_profile_begin(pfq_tree *tree, uint32_t max_calls);
+int pfq_profile_end(pfq_tree *tree, pfq_profile *out);
+
+/* K1 parity hook: the num_hashes bit indices of every canonical k-mer of `seq` (HOST buffers), exactly what
+ * BloomFilter::contains probes (bloom_filter.rs:312-332 via hash_iter.rs:13-45): out_idx[(kmer * num_hashes) + i]. */
+int pfq_debug_kmer_indices(pfq_tree *tree, const uint8_t *seq, uint64_t len, uint64_t *out_idx, uint64_t *n_kmers);
+/* Copy one node's filter words (Lsb0 u64, bloom_filter.rs:86) to the host; node = pre-order index. */
+int pfq_debug_node_filter(pfq_tree *tree, uint64_t node, uint64_t *out_words, uint64_t n_words);
+
+/* Synthetic workload generators of SURVEY §8d on the device (counter-based splitmix64); bench/test data only. */
+int pfq_synth_genomes_device(uint8_t *d_out, uint64_t n_genomes, uint64_t genome_len, uint64_t seed_base,
+                             void *stream);
+int pfq_synth_reads_device(uint8_t *d_out, uint64_t first_read, uint64_t n_reads, uint64_t read_len,
+                           const uint8_t *d_genomes, uint64_t genome_len, uint64_t n_genomes, uint64_t seed,
+                           void *stream);
+
+const char *pfq_last_error(void);
+const char *pfq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFQ_H */

@@ -263,23 +263,19 @@ def bf_contains(tree: OracleTree, filter_row: int, item: bytes) -> bool:
                                       tree.seed2, item, len(item)))
 
 
-def build_balanced_tree(genomes: Sequence[bytes], tax_ids: Sequence[str], kmer_size: int, nbits: int,
-                        num_hashes: int, seed1: int, seed2: int, fpr: float = 0.001,
-                        largest: int = 1000000) -> OracleTree:
-    """Synthetic SBT of SURVEY §8d: complete-as-possible balanced binary tree over the genomes in order,
-    internal filter = OR of children (node_union, bloom_tree.rs:238-239), unique internal names.
-    NOT the reference's greedy `insert` (out of scope); produces trees the reference's `query` accepts."""
-    g = len(genomes)
+def balanced_topology(tax_ids: Sequence[str], kmer_size: int, nbits: int, num_hashes: int, seed1: int, seed2: int,
+                      fpr: float = 0.001, largest: int = 1000000, alloc_bits: bool = True) -> OracleTree:
+    """Shape and naming of the synthetic SBT of SURVEY §8d (same numbering as libpfq's balanced builder):
+    complete-as-possible balanced binary tree over the leaves in order, nodes in pre-order, internal nodes named
+    Internal_Node_<pre-order counter>, one filter row per node."""
+    g = len(tax_ids)
     t = OracleTree(kmer_size, nbits, num_hashes, seed1, seed2, fpr, largest)
-    n_nodes = 2 * g - 1 if g else 0
-    t.bits = np.zeros((max(n_nodes, 1), t.n_words), dtype=np.uint64)
     counter = [0]
 
     def rec(lo: int, hi: int) -> int:
         if hi - lo == 1:
             v = t.add_node(tax_ids[lo], f"{tax_ids[lo]}.bf", -1)
             t.filter_of[v] = v
-            insert_sequence(t, v, genomes[lo])
             return v
         name = f"Internal_Node_{counter[0]}"
         counter[0] += 1
@@ -289,11 +285,28 @@ def build_balanced_tree(genomes: Sequence[bytes], tax_ids: Sequence[str], kmer_s
         l = rec(lo, mid)
         r = rec(mid, hi)
         t.left[v], t.right[v] = l, r
-        t.bits[v] = t.bits[l] | t.bits[r]
         return v
 
     if g:
         t.root = rec(0, g)
+    if alloc_bits:
+        t.bits = np.zeros((max(t.n_nodes, 1), t.n_words), dtype=np.uint64)
+    return t
+
+
+def build_balanced_tree(genomes: Sequence[bytes], tax_ids: Sequence[str], kmer_size: int, nbits: int,
+                        num_hashes: int, seed1: int, seed2: int, fpr: float = 0.001,
+                        largest: int = 1000000) -> OracleTree:
+    """Synthetic SBT of SURVEY §8d: leaf filters by init_leaf_node's insertion (bloom_tree.rs:154-168), internal
+    filter = OR of children (node_union, bloom_tree.rs:238-239).  NOT the reference's greedy `insert` (out of
+    scope); produces trees the reference's `query` accepts."""
+    t = balanced_topology(tax_ids, kmer_size, nbits, num_hashes, seed1, seed2, fpr, largest)
+    leaves = t.leaves_dfs()
+    for i, v in enumerate(leaves):
+        insert_sequence(t, v, genomes[i])
+    for v in reversed(range(t.n_nodes)):  # pre-order numbering: children have larger indices than their parent
+        if not t.is_leaf(v):
+            t.bits[v] = t.bits[t.left[v]] | t.bits[t.right[v]]
     return t
 
 

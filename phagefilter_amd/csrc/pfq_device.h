@@ -1,0 +1,215 @@
+// pfq_device.h — device-side building blocks of the classification path (gfx950 only).
+//
+//   K1  canonical k-mer + seeded FxHash + double hashing + exact `% nbits`
+//       replaces file_parser.rs:114-148 (get_lex_less/get_kmers), hasher.rs:12-21, hash_iter.rs:13-45 and the
+//       `h % self.bits.len()` of bloom_filter.rs:319.  k-mers are never materialised: a wave stages a 64-k-mer
+//       window of the read (forward bytes + reverse-complement bytes) in LDS and every lane hashes one k-mer
+//       straight out of LDS; the num_hashes indices live in registers only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pfq {
+
+// ---- tree-wide constants handed to every kernel (by value) -------------------------------------------------
+struct HashParams {
+    uint32_t k;           // kmer_size (1..PFQ_KMAX)
+    uint32_t num_hashes;  // 2..200 (bloom_filter.rs:342-350)
+    uint64_t nbits;       // d  (< 2^32)
+    uint64_t bar_m;       // floor((2^64-1)/d)  Barrett multiplier
+    uint64_t w64;         // 2^64 mod d
+    uint64_t a1, a2;      // (seed_s*K + k)*K : FxHasher state after write_usize(seed), write_usize(len)
+};
+
+constexpr uint32_t KMAX = 64;                        // supported k-mer length on the device path
+constexpr uint32_t WIN_KMERS = 64;                   // k-mers per window = lanes per wave
+constexpr uint32_t WIN_PAD = 8;                      // slack so aligned dword over-reads stay inside the window
+constexpr uint32_t WIN_BYTES = 160;                  // >= WIN_PAD + (WIN_KMERS + KMAX - 1) + WIN_PAD, dword multiple
+constexpr uint32_t WIN_DWORDS = WIN_BYTES / 4;
+constexpr uint32_t WAVES_PER_BLOCK = 4;
+
+constexpr uint64_t FX_K = 0xf1357aea2e62a9c5ull;      // rustc-hash 2.1 (64-bit)
+constexpr uint64_t FX_SEED1 = 0x243f6a8885a308d3ull;
+constexpr uint64_t FX_SEED2 = 0x13198a2e03707344ull;
+constexpr uint64_t FX_PTZC = 0xa4093822299f31d0ull;
+
+// LDS of one block: per-wave forward / reverse-complement windows + the shared complement table.
+struct BlockLds {
+    uint32_t win[WAVES_PER_BLOCK][2][WIN_DWORDS];
+    uint8_t comp[256];
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+// bio::alphabets::dna complement (bio 2.2.0; used by file_parser.rs:115): identity except the IUPAC pairs and
+// their lowercase forms.  Filled once per block.
+__device__ __forceinline__ void fill_complement(uint8_t *comp) {
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+        uint32_t u = i & ~32u, o = 0;  // u in 'A'..'Z' only if i is a letter (either case)
+        switch (u) {
+            case 'A': o = 'T'; break; case 'T': o = 'A'; break; case 'G': o = 'C'; break; case 'C': o = 'G'; break;
+            case 'Y': o = 'R'; break; case 'R': o = 'Y'; break; case 'W': o = 'W'; break; case 'S': o = 'S'; break;
+            case 'K': o = 'M'; break; case 'M': o = 'K'; break; case 'D': o = 'H'; break; case 'H': o = 'D'; break;
+            case 'V': o = 'B'; break; case 'B': o = 'V'; break; case 'N': o = 'N'; break;
+            default: break;
+        }
+        comp[i] = (uint8_t)(o ? (o | (i & 32u)) : i);  // mapped letters keep the input's case
+    }
+}
+
+// ---- LDS byte-granular reads ----------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lds_u32(const uint32_t *w, uint32_t a) {  // unaligned little-endian u32
+    uint32_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(w[i + 1], w[i], a & 3u);
+}
+__device__ __forceinline__ uint64_t lds_u64(const uint32_t *w, uint32_t a) {  // unaligned little-endian u64
+    uint32_t i = a >> 2, s = a & 3u;
+    uint32_t d0 = w[i], d1 = w[i + 1], d2 = w[i + 2];
+    uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, s), hi = __builtin_amdgcn_alignbyte(d2, d1, s);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t lds_u8(const uint32_t *w, uint32_t a) { return (w[a >> 2] >> (8u * (a & 3u))) & 0xffu; }
+
+// ---- window staging ---------------------------------------------------------------------------------------------
+// Stage k-mers [base, base+cnt) of a read (cnt <= 64): forward bytes read[base .. base+cnt+k-1) at fwd[WIN_PAD..]
+// and their reverse complement at rc[WIN_PAD..].  The k-mer at window position q is fwd[WIN_PAD+q, +k) and its
+// reverse complement is rc[WIN_PAD + W-q-k, +k), W = cnt+k-1.  Whole wave must call this convergently.
+__device__ __forceinline__ void stage_window(BlockLds &lds, uint32_t wave, const uint8_t *__restrict__ read,
+                                             uint64_t base, uint32_t cnt, uint32_t k) {
+    uint32_t lane = lane_id();
+    uint32_t W = cnt + k - 1;  // <= 127
+    uint8_t *fwd = reinterpret_cast<uint8_t *>(lds.win[wave][0]);
+    uint8_t *rc = reinterpret_cast<uint8_t *>(lds.win[wave][1]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (uint32_t j = lane; j < WIN_KMERS + KMAX - 1; j += 64) {
+        if (j < W) {
+            uint8_t b = read[base + j];
+            fwd[WIN_PAD + j] = b;
+            rc[WIN_PAD + (W - 1 - j)] = lds.comp[b];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- rustc-hash 2.1 ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t fx_mm(uint64_t x, uint64_t y) { return (x * y) ^ __umul64hi(x, y); }
+
+// hash_bytes over n bytes at byte address `a` of LDS word array `w` (n is wave-uniform).
+__device__ __forceinline__ uint64_t fx_hash_bytes_lds(const uint32_t *w, uint32_t a, uint32_t n) {
+    uint64_t s0 = FX_SEED1, s1 = FX_SEED2;
+    if (n <= 16) {
+        if (n >= 8) {
+            s0 ^= lds_u64(w, a);
+            s1 ^= lds_u64(w, a + n - 8);
+        } else if (n >= 4) {
+            s0 ^= lds_u32(w, a);
+            s1 ^= lds_u32(w, a + n - 4);
+        } else if (n > 0) {
+            uint64_t lo = lds_u8(w, a), mid = lds_u8(w, a + n / 2), hi = lds_u8(w, a + n - 1);
+            s0 ^= lo;
+            s1 ^= (hi << 8) | mid;
+        }
+    } else {
+        uint32_t off = 0;
+        while (off < n - 16) {
+            uint64_t x = lds_u64(w, a + off), y = lds_u64(w, a + off + 8);
+            uint64_t t = fx_mm(s0 ^ x, FX_PTZC ^ y);
+            s0 = s1;
+            s1 = t;
+            off += 16;
+        }
+        s0 ^= lds_u64(w, a + n - 16);
+        s1 ^= lds_u64(w, a + n - 8);
+    }
+    return fx_mm(s0, s1) ^ (uint64_t)n;
+}
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, uint32_t r) { return (x << r) | (x >> (64 - r)); }
+
+// The two seeded hashes of the canonical k-mer at window position q (per lane).
+// Canonical choice (file_parser.rs:116-120): forward unless revcomp is bytewise smaller.
+__device__ __forceinline__ void kmer_hashes(const BlockLds &lds, uint32_t wave, uint32_t q, uint32_t cnt, bool valid,
+                                            const HashParams &hp, uint64_t &h1, uint64_t &h2) {
+    const uint32_t *fw = lds.win[wave][0], *rw = lds.win[wave][1];
+    uint32_t k = hp.k, W = cnt + k - 1;
+    uint32_t fa = WIN_PAD + q, ra = WIN_PAD + (W - q - k);
+    if (!valid) { fa = WIN_PAD; ra = WIN_PAD; }
+    // bytewise lexicographic compare == compare of byte-swapped dwords, first difference decides
+    bool use_rc = false, decided = !valid;
+    for (uint32_t j = 0; j < k; j += 4) {
+        uint32_t f = lds_u32(fw, fa + j), r = lds_u32(rw, ra + j);
+        uint32_t rem = k - j;
+        if (rem < 4) { uint32_t m = (1u << (8u * rem)) - 1u; f &= m; r &= m; }
+        if (!decided && f != r) {
+            use_rc = __builtin_bswap32(r) < __builtin_bswap32(f);
+            decided = true;
+        }
+        if (ballot64(!decided) == 0) break;
+    }
+    const uint32_t *cw = use_rc ? rw : fw;
+    uint32_t ca = use_rc ? ra : fa;
+    uint64_t hb = fx_hash_bytes_lds(cw, ca, k);
+    h1 = rotl64((hp.a1 + hb) * FX_K, 26);
+    h2 = rotl64((hp.a2 + hb) * FX_K, 26);
+}
+
+// ---- exact `% nbits` ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mod_nbits(uint64_t r, const HashParams &hp) {
+    uint64_t q = __umul64hi(r, hp.bar_m);
+    uint64_t rem = r - q * hp.nbits;  // in [0, 2d]
+    rem -= (rem >= hp.nbits) ? hp.nbits : 0;
+    rem -= (rem >= hp.nbits) ? hp.nbits : 0;
+    return (uint32_t)rem;
+}
+
+// Iterator over the probe indices of one k-mer: i=0 -> h1 % d, i=1 -> h2 % d, i>=2 -> ((h1+i)*h2 mod 2^64) % d
+// (hash_iter.rs:13-27, bloom_filter.rs:319).  For i >= 3 the value advances by +h2 (mod 2^64), so the residue
+// advances by (h2 % d) and, when the 64-bit add wraps, by -(2^64 % d): no further wide multiplies.
+struct ProbeIter {
+    uint64_t r, h2;
+    uint32_t x, g, i0;
+    __device__ __forceinline__ void init(uint64_t h1, uint64_t h2_, const HashParams &hp) {
+        h2 = h2_;
+        i0 = mod_nbits(h1, hp);
+        g = mod_nbits(h2_, hp);
+        r = (h1 + 2) * h2_;
+        x = mod_nbits(r, hp);
+    }
+    // Must be called with i = 0, 1, 2, ... in order; i is wave-uniform (a loop counter).
+    __device__ __forceinline__ uint32_t get(uint32_t i, const HashParams &hp) {
+        if (i == 0) return i0;
+        if (i == 1) return g;
+        if (i == 2) return x;
+        uint64_t rn = r + h2;
+        bool carry = rn < r;
+        r = rn;
+        uint64_t t = (uint64_t)x + g + (carry ? (hp.nbits - hp.w64) : 0ull);  // < 3d
+        t -= (t >= hp.nbits) ? hp.nbits : 0;
+        t -= (t >= hp.nbits) ? hp.nbits : 0;
+        x = (uint32_t)t;
+        return x;
+    }
+};
+
+// `(threshold * n as f32).ceil() as usize` (query.rs:48): IEEE f32 multiply (no contraction possible: single op),
+// ceil, Rust's saturating float->int cast (NaN -> 0).
+__device__ __forceinline__ uint64_t need_kmers(float threshold, uint64_t n) {
+    float c = ceilf(__fmul_rn(threshold, (float)n));
+    if (!(c > 0.0f)) return 0;
+    if (c >= 18446744073709551616.0f) return ~0ull;
+    return (uint64_t)c;
+}
+
+// ---- synthetic workload PRNG (mirrors oracle/pfq_oracle.c) --------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint64_t rnd(uint64_t seed, uint64_t i) { return splitmix64(splitmix64(seed) + i); }
+
+}  // namespace pfq

@@ -1,0 +1,1030 @@
+// pfq_host.cpp — host side of libpfq: the tree model (BloomTree/BloomNode, bloom_tree.rs:29-61), the
+// tree.bin / .bf reader and writer (bincode 1.3.3 + bitvec 1.0.1 layouts, bloom_tree.rs:339-386,
+// bloom_filter.rs:153-205), the HBM layout builder and the query orchestration behind the C ABI of include/pfq.h.
+// Compiled with hipcc together with pfq_kernels.hip.  No CPU compute path exists here: all filter work is
+// done by the kernels and every entry point fails with PFQ_ERR_DEVICE when no gfx950 device is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pfq.h"
+#include "pfq_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(PFQ_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                                            std::to_string(__LINE__) + ")");                                 \
+    } while (0)
+#define PFQ_TRY(expr)              \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != PFQ_OK) return rc_; \
+    } while (0)
+
+struct Node {
+    int32_t left = -1, right = -1, parent = -1;
+    std::string bf_path;  // relative file name, joined to the db dir like cache.rs:62
+    bool has_tax = false;
+    std::string tax_id;
+    uint64_t mapped_reads = 0;
+    uint32_t filter = 0;  // row of d_bits
+    uint32_t depth = 0;
+    bool is_leaf() const { return left < 0 && right < 0; }  // bloom_tree.rs:416-418
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t ensure(size_t want) {
+        if (want <= n) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&p, want * sizeof(T));
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+}  // namespace
+
+struct pfq_tree {
+    int device = 0;
+    // ---- model
+    std::vector<Node> nodes;  // pre-order, root = 0
+    int32_t root = -1;
+    float false_pos_rate = 0.001f;
+    uint32_t largest_expected_genome = 0;
+    uint64_t kmer_size = 0, nbits = 0, seed1 = 0, seed2 = 0, n_words = 0;
+    uint32_t num_hashes = 0;
+    std::vector<std::string> filter_paths;
+    std::vector<uint8_t> edge_ok;  // per node: parent(v) ⊇ v verified
+    bool superset_all = true;
+    pfq::HashParams hp{};
+    // ---- device: node-major filters
+    DevBuf<uint64_t> d_bits;
+    // ---- device: layout of the current leaf set
+    bool layout_valid = false;
+    std::vector<int32_t> leaves;     // node ids, left-to-right
+    std::vector<uint32_t> col_row;   // column -> filter row
+    std::vector<uint32_t> guard_off, guard_col;
+    uint32_t rw = 1, rw_log2 = 0, n_cols = 0;
+    DevBuf<uint32_t> d_S, d_col_row, d_guard_off, d_guard_col;
+    DevBuf<unsigned long long> d_counts;
+    // ---- query scratch
+    DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit cursor, [1] pair cursor
+    DevBuf<uint2> d_hit_pairs, d_pairs, d_sorted;
+    DevBuf<uint32_t> d_bucket, d_fail;  // bucket: cnt[n], off[n+1], cur[n]
+    DevBuf<unsigned int> d_queue;
+    DevBuf<uint8_t> d_allhit, d_seq;
+    DevBuf<uint64_t> d_off;
+    DevBuf<unsigned long long> d_counts_snapshot;
+    hipStream_t last_stream = nullptr;
+    int force_path = -1;
+    // ---- profiling (HIP events on the launch stream)
+    std::vector<hipEvent_t> prof_ev;  // 5 events per recorded call
+    size_t prof_cap = 0, prof_used = 0;
+    std::vector<uint8_t> prof_bucketed;
+    uint32_t last_path = 0, last_slices = 1;
+    uint64_t last_n_reads = 0;
+    // ---- outputs (library-owned)
+    std::vector<std::string> out_tax;
+    std::vector<const char *> out_tax_ptr;
+    std::vector<uint64_t> out_counts, hit_offsets;
+    std::vector<uint32_t> hit_leaves;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------
+// bincode cursor
+// ------------------------------------------------------------------------------------------------------------
+struct Cur {
+    const uint8_t *b;
+    size_t n, p = 0;
+    bool ok = true;
+    const uint8_t *take(size_t k) {
+        if (!ok || k > n - p) {
+            ok = false;
+            return nullptr;
+        }
+        const uint8_t *r = b + p;
+        p += k;
+        return r;
+    }
+    uint8_t u8() { auto q = take(1); return q ? *q : 0; }
+    uint32_t u32() { auto q = take(4); uint32_t v = 0; if (q) memcpy(&v, q, 4); return v; }
+    uint64_t u64() { auto q = take(8); uint64_t v = 0; if (q) memcpy(&v, q, 8); return v; }
+    float f32() { auto q = take(4); float v = 0; if (q) memcpy(&v, q, 4); return v; }
+    std::string str() {
+        uint64_t len = u64();
+        if (!ok || len > n - p) { ok = false; return {}; }
+        auto q = take((size_t)len);
+        return q ? std::string((const char *)q, (size_t)len) : std::string();
+    }
+};
+
+bool read_file(const std::string &path, std::vector<uint8_t> &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize(sz > 0 ? (size_t)sz : 0);
+    size_t got = out.empty() ? 0 : fread(out.data(), 1, out.size(), f);
+    fclose(f);
+    return got == out.size();
+}
+
+// BloomNode, pre-order (bloom_tree.rs:50-61): left, right, bloom_filter_path, tax_id, mapped_reads
+int parse_node(Cur &c, pfq_tree &t, int32_t parent, uint32_t depth, int32_t &out_idx) {
+    if (depth > 100000) return fail(PFQ_ERR_FORMAT, "tree.bin: nesting too deep");
+    int32_t v = (int32_t)t.nodes.size();
+    t.nodes.emplace_back();
+    t.nodes[v].parent = parent;
+    t.nodes[v].depth = depth;
+    for (int side = 0; side < 2; ++side) {
+        uint8_t tag = c.u8();
+        if (!c.ok || tag > 1) return fail(PFQ_ERR_FORMAT, "tree.bin: bad Option tag in BloomNode");
+        int32_t child = -1;
+        if (tag == 1) PFQ_TRY(parse_node(c, t, v, depth + 1, child));
+        (side == 0 ? t.nodes[v].left : t.nodes[v].right) = child;
+    }
+    t.nodes[v].bf_path = c.str();
+    uint8_t tag = c.u8();
+    if (!c.ok || tag > 1) return fail(PFQ_ERR_FORMAT, "tree.bin: bad Option tag for tax_id");
+    if (tag == 1) {
+        t.nodes[v].has_tax = true;
+        t.nodes[v].tax_id = c.str();
+    }
+    t.nodes[v].mapped_reads = c.u64();
+    if (!c.ok) return fail(PFQ_ERR_FORMAT, "tree.bin: truncated BloomNode");
+    out_idx = v;
+    return PFQ_OK;
+}
+
+uint64_t pow2_64_mod(uint64_t d) {  // 2^64 mod d
+    uint64_t r = (~0ull) % d;       // (2^64 - 1) mod d
+    return (r + 1 == d) ? 0 : r + 1;
+}
+
+int setup_hash_params(pfq_tree &t) {
+    if (t.kmer_size < 1 || t.kmer_size > pfq::KMAX)
+        return fail(PFQ_ERR_UNSUPPORTED, "kmer_size " + std::to_string(t.kmer_size) + " outside the device path's 1.." +
+                                              std::to_string(pfq::KMAX));
+    if (t.nbits < 1 || t.nbits >= (1ull << 32))
+        return fail(PFQ_ERR_UNSUPPORTED, "filter size " + std::to_string(t.nbits) + " bits outside 1..2^32-1");
+    if (t.num_hashes < 1) return fail(PFQ_ERR_FORMAT, "num_hashes == 0");
+    t.n_words = (t.nbits + 63) / 64;
+    t.hp.k = (uint32_t)t.kmer_size;
+    t.hp.num_hashes = t.num_hashes;
+    t.hp.nbits = t.nbits;
+    t.hp.bar_m = (~0ull) / t.nbits;
+    t.hp.w64 = pow2_64_mod(t.nbits);
+    // FxHasher after write_usize(seed) (hasher.rs:16-18) and the length prefix of <[u8] as Hash>::hash
+    t.hp.a1 = (t.seed1 * pfq::FX_K + t.kmer_size) * pfq::FX_K;
+    t.hp.a2 = (t.seed2 * pfq::FX_K + t.kmer_size) * pfq::FX_K;
+    return PFQ_OK;
+}
+
+int use_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(PFQ_ERR_DEVICE, "no HIP device available (libpfq has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(PFQ_ERR_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    return PFQ_OK;
+}
+
+void relink(pfq_tree &t) {  // parent/depth after topology edits
+    if (t.root < 0) return;
+    std::vector<int32_t> st{t.root};
+    t.nodes[t.root].parent = -1;
+    t.nodes[t.root].depth = 0;
+    while (!st.empty()) {
+        int32_t v = st.back();
+        st.pop_back();
+        for (int32_t c : {t.nodes[v].left, t.nodes[v].right})
+            if (c >= 0) {
+                t.nodes[c].parent = v;
+                t.nodes[c].depth = t.nodes[v].depth + 1;
+                st.push_back(c);
+            }
+    }
+}
+
+std::vector<int32_t> leaves_dfs(const pfq_tree &t) {  // get_leaf_counts order, query.rs:197-218
+    std::vector<int32_t> out;
+    if (t.root < 0) return out;
+    std::vector<int32_t> st{t.root};
+    while (!st.empty()) {
+        int32_t v = st.back();
+        st.pop_back();
+        const Node &nd = t.nodes[v];
+        if (nd.is_leaf()) out.push_back(v);
+        else {
+            if (nd.right >= 0) st.push_back(nd.right);
+            if (nd.left >= 0) st.push_back(nd.left);
+        }
+    }
+    return out;
+}
+
+// Fold the device counters back into BloomNode::mapped_reads (before the leaf set changes / on read-out).
+int sync_counts_to_nodes(pfq_tree &t) {
+    if (!t.layout_valid || t.leaves.empty()) return PFQ_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(t.leaves.size());
+    HIP_TRY(hipMemcpy(h.data(), t.d_counts.p, h.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); ++i) t.nodes[t.leaves[i]].mapped_reads = h[i];
+    return PFQ_OK;
+}
+
+// parent ⊇ child on every edge of the full tree, on the device.
+int verify_supersets(pfq_tree &t) {
+    t.edge_ok.assign(t.nodes.size(), 1);
+    t.superset_all = true;
+    std::vector<uint32_t> edges;
+    std::vector<int32_t> edge_node;
+    for (size_t v = 0; v < t.nodes.size(); ++v)
+        if (t.nodes[v].parent >= 0 && t.nodes[t.nodes[v].parent].filter != t.nodes[v].filter) {
+            edges.push_back(t.nodes[t.nodes[v].parent].filter);
+            edges.push_back(t.nodes[v].filter);
+            edge_node.push_back((int32_t)v);
+        }
+    if (edge_node.empty()) return PFQ_OK;
+    DevBuf<uint32_t> d_edges, d_fail;
+    HIP_TRY(d_edges.ensure(edges.size()));
+    HIP_TRY(d_fail.ensure(edge_node.size()));
+    HIP_TRY(hipMemcpy(d_edges.p, edges.data(), edges.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_fail.p, 0, edge_node.size() * 4));
+    // blockIdx.y is limited to 65535
+    for (size_t e0 = 0; e0 < edge_node.size(); e0 += 32768) {
+        uint32_t ne = (uint32_t)std::min<size_t>(32768, edge_node.size() - e0);
+        pfq::launch_superset(t.d_bits.p, t.n_words, d_edges.p + 2 * e0, ne, d_fail.p + e0, nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> h(edge_node.size());
+    HIP_TRY(hipMemcpy(h.data(), d_fail.p, h.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); ++i)
+        if (h[i]) {
+            t.edge_ok[edge_node[i]] = 0;
+            t.superset_all = false;
+        }
+    return PFQ_OK;
+}
+
+// Build the sliced matrix for the current leaf set.
+int build_layout(pfq_tree &t) {
+    if (t.layout_valid) return PFQ_OK;
+    t.leaves = leaves_dfs(t);
+    const size_t nl = t.leaves.size();
+    for (int32_t v : t.leaves)
+        if (!t.nodes[v].has_tax)
+            return fail(PFQ_ERR_FORMAT, "leaf node without tax_id (reference: unwrap panic, query.rs:146)");
+    t.col_row.clear();
+    t.guard_off.assign(nl + 1, 0);
+    t.guard_col.clear();
+    std::map<uint32_t, uint32_t> guard_column_of_row;  // filter row -> guard column
+    std::vector<uint32_t> guard_rows;
+    for (size_t i = 0; i < nl; ++i) {
+        t.col_row.push_back(t.nodes[t.leaves[i]].filter);
+        bool ok = true;
+        for (int32_t v = t.leaves[i]; t.nodes[v].parent >= 0; v = t.nodes[v].parent) {
+            ok = ok && t.edge_ok[v];
+            if (!ok) {
+                uint32_t row = t.nodes[t.nodes[v].parent].filter;
+                if (row == t.nodes[t.leaves[i]].filter) continue;  // same filter as the leaf itself
+                auto it = guard_column_of_row.find(row);
+                uint32_t col;
+                if (it == guard_column_of_row.end()) {
+                    col = (uint32_t)(nl + guard_rows.size());
+                    guard_column_of_row[row] = col;
+                    guard_rows.push_back(row);
+                } else col = it->second;
+                if (std::find(t.guard_col.begin() + t.guard_off[i], t.guard_col.end(), col) == t.guard_col.end())
+                    t.guard_col.push_back(col);
+            }
+        }
+        t.guard_off[i + 1] = (uint32_t)t.guard_col.size();
+    }
+    for (uint32_t r : guard_rows) t.col_row.push_back(r);
+    t.n_cols = (uint32_t)t.col_row.size();
+    uint32_t need_words = std::max<uint32_t>(1, (t.n_cols + 31) / 32);
+    t.rw = 1;
+    t.rw_log2 = 0;
+    while (t.rw < need_words) {
+        t.rw <<= 1;
+        ++t.rw_log2;
+    }
+    if (t.rw > 64)
+        return fail(PFQ_ERR_UNSUPPORTED, "tree has " + std::to_string(t.n_cols) +
+                                             " leaf+guard columns; this build supports at most 2048 (DESIGN.md §6)");
+    if (nl == 0) {
+        t.layout_valid = true;
+        return PFQ_OK;
+    }
+    const size_t s_words = (size_t)t.n_words * 64 * t.rw;
+    HIP_TRY(t.d_S.ensure(s_words));
+    HIP_TRY(t.d_col_row.ensure(t.col_row.size()));
+    HIP_TRY(t.d_guard_off.ensure(t.guard_off.size() + t.n_cols));  // guard lists are indexed by column; pad for guard columns
+    HIP_TRY(t.d_guard_col.ensure(std::max<size_t>(1, t.guard_col.size())));
+    HIP_TRY(t.d_counts.ensure(nl));
+    HIP_TRY(hipMemcpy(t.d_col_row.p, t.col_row.data(), t.col_row.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_guard_off.p, t.guard_off.data(), t.guard_off.size() * 4, hipMemcpyHostToDevice));
+    if (!t.guard_col.empty())
+        HIP_TRY(hipMemcpy(t.d_guard_col.p, t.guard_col.data(), t.guard_col.size() * 4, hipMemcpyHostToDevice));
+    std::vector<unsigned long long> h(nl);
+    for (size_t i = 0; i < nl; ++i) h[i] = t.nodes[t.leaves[i]].mapped_reads;
+    HIP_TRY(hipMemcpy(t.d_counts.p, h.data(), nl * 8, hipMemcpyHostToDevice));
+    if (t.rw * 32 > t.n_cols || true) HIP_TRY(hipMemsetAsync(t.d_S.p, 0, s_words * 4, nullptr));
+    pfq::launch_transpose(t.d_bits.p, t.n_words, t.d_col_row.p, t.n_cols, t.d_S.p, t.rw, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    t.layout_valid = true;
+    return PFQ_OK;
+}
+
+int ensure_scratch(pfq_tree &t, uint64_t n_reads, bool want_hits) {
+    HIP_TRY(t.d_stats.ensure(pfq::ST_N));
+    HIP_TRY(t.d_cursors.ensure(2));
+    const uint64_t cap = 2 * n_reads + 1024;
+    if (want_hits) {
+        HIP_TRY(t.d_hit_pairs.ensure(cap));
+        HIP_TRY(t.d_allhit.ensure(n_reads + 1));
+        HIP_TRY(t.d_counts_snapshot.ensure(t.leaves.size() + 1));
+    }
+    return PFQ_OK;
+}
+int ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads) {
+    const uint64_t cap = 2 * n_reads + 1024;
+    HIP_TRY(t.d_pairs.ensure(cap));
+    HIP_TRY(t.d_sorted.ensure(cap));
+    HIP_TRY(t.d_fail.ensure(cap));
+    HIP_TRY(t.d_bucket.ensure(3 * t.leaves.size() + 2));
+    HIP_TRY(t.d_queue.ensure(16));
+    return PFQ_OK;
+}
+
+constexpr uint64_t BUCKET_MIN_READS = 1ull << 18;  // below this the bucketed pass cannot amortise warming the L2 slices
+constexpr uint64_t SLICE_TARGET_BYTES = 2560ull << 10;
+
+int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint64_t n_reads, float threshold,
+                 uint32_t flags, hipStream_t st, pfq_hits *hits) {
+    if (t.root < 0) return fail(PFQ_ERR_STATE, "query on an empty tree");
+    PFQ_TRY(build_layout(t));
+    const bool want_hits = (flags & PFQ_WANT_HITS) != 0;
+    if (want_hits && !hits) return fail(PFQ_ERR_ARG, "PFQ_WANT_HITS set but hits == NULL");
+    if (n_reads >= (1ull << 31) - 1024) return fail(PFQ_ERR_ARG, "more than 2^31 reads in one block");
+    t.last_stream = st;
+    t.last_n_reads = n_reads;
+    PFQ_TRY(ensure_scratch(t, n_reads, want_hits));
+    const size_t nl = t.leaves.size();
+    bool bucketed = (t.force_path == 1) ||
+                    (t.force_path < 0 && threshold == 1.0f && n_reads >= BUCKET_MIN_READS);
+    if (!(threshold == 1.0f) || !t.guard_col.empty() || nl == 0) bucketed = false;
+    if (bucketed) PFQ_TRY(ensure_bucket_scratch(t, n_reads));
+    t.last_path = bucketed ? 1 : 0;
+
+    uint64_t hit_cap = t.d_hit_pairs.n;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(hipMemsetAsync(t.d_stats.p, 0, pfq::ST_N * 8, st));
+        HIP_TRY(hipMemsetAsync(t.d_cursors.p, 0, 16, st));
+        if (want_hits) {
+            HIP_TRY(hipMemsetAsync(t.d_allhit.p, 0, n_reads + 1, st));
+            if (attempt == 0 && nl)
+                HIP_TRY(hipMemcpyAsync(t.d_counts_snapshot.p, t.d_counts.p, nl * 8, hipMemcpyDeviceToDevice, st));
+        }
+        if (n_reads && nl) {
+            pfq::QueryArgs a{};
+            a.hp = t.hp;
+            a.seq = d_seq;
+            a.off = d_off;
+            a.n_reads = n_reads;
+            a.threshold = threshold;
+            a.S = t.d_S.p;
+            a.rw = t.rw;
+            a.rw_log2 = t.rw_log2;
+            a.n_leaves = (uint32_t)nl;
+            a.n_cols = t.n_cols;
+            a.guard_off = t.d_guard_off.p;
+            a.guard_col = t.d_guard_col.p;
+            a.counts = t.d_counts.p;
+            a.hit_pairs = want_hits ? t.d_hit_pairs.p : nullptr;
+            a.hit_cap = hit_cap;
+            a.hit_cursor = t.d_cursors.p;
+            a.allhit_flag = want_hits ? t.d_allhit.p : nullptr;
+            a.stats = t.d_stats.p;
+            int blocks = (int)std::min<uint64_t>((n_reads + 3) / 4, 2048);
+            const bool counts_mode = !(threshold >= 1.0f);  // theta >= 1: need >= n for every read with k-mers
+            hipEvent_t *ev = nullptr;
+            if (t.prof_used < t.prof_cap) {
+                ev = &t.prof_ev[5 * t.prof_used];
+                t.prof_bucketed[t.prof_used] = bucketed;
+                ++t.prof_used;
+            }
+            if (ev) HIP_TRY(hipEventRecord(ev[0], st));
+            if (bucketed) {
+                uint32_t *cnt = t.d_bucket.p, *off = cnt + nl, *cur = off + nl + 1;
+                a.pairs = t.d_pairs.p;
+                a.pair_cap = t.d_pairs.n;
+                a.pair_cursor = t.d_cursors.p + 1;
+                a.bucket_cnt = cnt;
+                uint32_t n_slices = 1;
+                while (n_slices < 8 && (t.n_words * 8 + n_slices - 1) / n_slices > SLICE_TARGET_BYTES) n_slices <<= 1;
+                t.last_slices = n_slices;
+                HIP_TRY(hipMemsetAsync(cnt, 0, nl * 4, st));
+                HIP_TRY(hipMemsetAsync(t.d_fail.p, 0, t.d_fail.n * 4, st));
+                HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 16 * 4, st));
+                pfq::launch_classify(a, true, false, blocks, st);
+                if (ev) HIP_TRY(hipEventRecord(ev[1], st));
+                pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nl, st);
+                pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, t.d_pairs.n, off, cur, t.d_sorted.p, 1024, st);
+                if (ev) HIP_TRY(hipEventRecord(ev[2], st));
+                pfq::VerifyArgs v{};
+                v.hp = t.hp;
+                v.seq = d_seq;
+                v.off = d_off;
+                v.bits = t.d_bits.p;
+                v.col_row = t.d_col_row.p;
+                v.n_words = t.n_words;
+                v.sorted = t.d_sorted.p;
+                v.n_pairs_ptr = t.d_cursors.p + 1;
+                v.pair_cap = t.d_pairs.n;
+                v.fail = t.d_fail.p;
+                v.n_slices = n_slices;
+                uint64_t sb = (t.n_words * 64 + n_slices - 1) / n_slices;
+                v.slice_bits = (uint32_t)((sb + 63) & ~63ull);
+                v.queue = t.d_queue.p;
+                v.chunk = 16;
+                pfq::launch_verify(v, 2048, st);
+                if (ev) HIP_TRY(hipEventRecord(ev[3], st));
+                pfq::FinalizeArgs f{};
+                f.hp = t.hp;
+                f.off = d_off;
+                f.sorted = t.d_sorted.p;
+                f.bucket_off = off;
+                f.fail = t.d_fail.p;
+                f.n_leaves = (uint32_t)nl;
+                f.counts = t.d_counts.p;
+                f.hit_pairs = a.hit_pairs;
+                f.hit_cap = hit_cap;
+                f.hit_cursor = t.d_cursors.p;
+                f.stats = t.d_stats.p;
+                pfq::launch_finalize(f, st);
+                if (ev) HIP_TRY(hipEventRecord(ev[4], st));
+            } else {
+                pfq::launch_classify(a, false, counts_mode, blocks, st);
+                if (ev) HIP_TRY(hipEventRecord(ev[1], st));
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        if (!want_hits) return PFQ_OK;
+        HIP_TRY(hipStreamSynchronize(st));
+        unsigned long long cursors[2] = {0, 0};
+        HIP_TRY(hipMemcpy(cursors, t.d_cursors.p, 16, hipMemcpyDeviceToHost));
+        if (cursors[0] <= hit_cap) {
+            // CSR read -> leaves (ascending), all-hit reads expand to every leaf
+            std::vector<uint2> pairs((size_t)cursors[0]);
+            if (!pairs.empty()) HIP_TRY(hipMemcpy(pairs.data(), t.d_hit_pairs.p, pairs.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<uint8_t> allhit((size_t)n_reads);
+            if (n_reads) HIP_TRY(hipMemcpy(allhit.data(), t.d_allhit.p, (size_t)n_reads, hipMemcpyDeviceToHost));
+            t.hit_offsets.assign((size_t)n_reads + 1, 0);
+            for (auto &p : pairs) ++t.hit_offsets[p.x + 1];
+            for (uint64_t r = 0; r < n_reads; ++r)
+                if (allhit[r]) t.hit_offsets[r + 1] = nl;
+            for (uint64_t r = 0; r < n_reads; ++r) t.hit_offsets[r + 1] += t.hit_offsets[r];
+            t.hit_leaves.assign((size_t)t.hit_offsets[n_reads], 0);
+            std::vector<uint64_t> fill(t.hit_offsets.begin(), t.hit_offsets.end() - 1);
+            for (auto &p : pairs) t.hit_leaves[fill[p.x]++] = p.y;
+            for (uint64_t r = 0; r < n_reads; ++r) {
+                if (allhit[r])
+                    for (uint32_t c = 0; c < nl; ++c) t.hit_leaves[t.hit_offsets[r] + c] = c;
+                else
+                    std::sort(t.hit_leaves.begin() + t.hit_offsets[r], t.hit_leaves.begin() + t.hit_offsets[r + 1]);
+            }
+            hits->n_reads = n_reads;
+            hits->offsets = t.hit_offsets.data();
+            hits->leaves = t.hit_leaves.data();
+            return PFQ_OK;
+        }
+        // hit buffer too small: restore the counters and run the block again with room for every hit
+        if (nl) HIP_TRY(hipMemcpy(t.d_counts.p, t.d_counts_snapshot.p, nl * 8, hipMemcpyDeviceToDevice));
+        HIP_TRY(t.d_hit_pairs.ensure(cursors[0] + 1024));
+        hit_cap = t.d_hit_pairs.n;
+    }
+    return fail(PFQ_ERR_DEVICE, "hit buffer overflow persisted");
+}
+
+// Balanced synthetic tree topology; same numbering as oracle/pfq_oracle.py:build_balanced_tree.
+int32_t build_balanced_rec(pfq_tree &t, const char *const *tax_ids, uint64_t lo, uint64_t hi, int32_t parent,
+                           uint32_t depth, uint64_t &internal_counter) {
+    int32_t v = (int32_t)t.nodes.size();
+    t.nodes.emplace_back();
+    t.nodes[v].parent = parent;
+    t.nodes[v].depth = depth;
+    t.nodes[v].filter = (uint32_t)v;
+    t.nodes[v].has_tax = true;
+    if (hi - lo == 1) {
+        t.nodes[v].tax_id = tax_ids[lo];
+        t.nodes[v].bf_path = t.nodes[v].tax_id + ".bf";
+        return v;
+    }
+    t.nodes[v].tax_id = "Internal_Node_" + std::to_string(internal_counter++);
+    t.nodes[v].bf_path = t.nodes[v].tax_id + ".bf";
+    uint64_t mid = lo + (hi - lo + 1) / 2;
+    int32_t l = build_balanced_rec(t, tax_ids, lo, mid, v, depth + 1, internal_counter);
+    int32_t r = build_balanced_rec(t, tax_ids, mid, hi, v, depth + 1, internal_counter);
+    t.nodes[v].left = l;
+    t.nodes[v].right = r;
+    return v;
+}
+
+int build_balanced_common(const uint8_t *d_genomes, const uint64_t *d_goff, uint64_t n_genomes, const char *const *tax_ids,
+                          uint64_t kmer_size, uint64_t nbits, uint32_t num_hashes, uint64_t seed1, uint64_t seed2,
+                          float fpr, uint32_t largest, int device, pfq_tree **out) {
+    std::unique_ptr<pfq_tree> t(new pfq_tree());
+    t->device = device;
+    t->kmer_size = kmer_size;
+    t->nbits = nbits;
+    t->num_hashes = num_hashes;
+    t->seed1 = seed1;
+    t->seed2 = seed2;
+    t->false_pos_rate = fpr;
+    t->largest_expected_genome = largest;
+    PFQ_TRY(setup_hash_params(*t));
+    if (n_genomes > 65535) return fail(PFQ_ERR_UNSUPPORTED, "more than 65535 genomes in one balanced build");
+    if (n_genomes) {
+        uint64_t counter = 0;
+        t->root = build_balanced_rec(*t, tax_ids, 0, n_genomes, -1, 0, counter);
+    }
+    const size_t nn = t->nodes.size();
+    for (auto &nd : t->nodes) t->filter_paths.push_back(nd.bf_path);
+    if (nn) {
+        HIP_TRY(t->d_bits.ensure(nn * t->n_words));
+        HIP_TRY(hipMemset(t->d_bits.p, 0, nn * t->n_words * 8));
+        // leaves: genome order == left-to-right leaf order
+        std::vector<int32_t> lv = leaves_dfs(*t);
+        std::vector<uint32_t> leaf_row(lv.size());
+        for (size_t i = 0; i < lv.size(); ++i) leaf_row[i] = t->nodes[lv[i]].filter;
+        DevBuf<uint32_t> d_leaf_row, d_triples;
+        HIP_TRY(d_leaf_row.ensure(leaf_row.size()));
+        HIP_TRY(hipMemcpy(d_leaf_row.p, leaf_row.data(), leaf_row.size() * 4, hipMemcpyHostToDevice));
+        pfq::launch_insert(t->hp, d_genomes, d_goff, (uint32_t)n_genomes, d_leaf_row.p, t->d_bits.p, t->n_words, nullptr);
+        HIP_TRY(hipGetLastError());
+        // internal nodes bottom-up, one launch per depth
+        uint32_t max_depth = 0;
+        for (auto &nd : t->nodes) max_depth = std::max(max_depth, nd.depth);
+        for (int d = (int)max_depth; d >= 0; --d) {
+            std::vector<uint32_t> triples;
+            for (size_t v = 0; v < nn; ++v) {
+                const Node &nd = t->nodes[v];
+                if ((int)nd.depth != d || nd.is_leaf()) continue;
+                triples.push_back(nd.filter);
+                triples.push_back(t->nodes[nd.left].filter);
+                triples.push_back(t->nodes[nd.right].filter);
+            }
+            if (triples.empty()) continue;
+            HIP_TRY(d_triples.ensure(triples.size()));
+            HIP_TRY(hipMemcpy(d_triples.p, triples.data(), triples.size() * 4, hipMemcpyHostToDevice));
+            for (size_t t0 = 0; t0 < triples.size() / 3; t0 += 32768) {
+                uint32_t nt = (uint32_t)std::min<size_t>(32768, triples.size() / 3 - t0);
+                pfq::launch_union(t->d_bits.p, t->n_words, d_triples.p + 3 * t0, nt, nullptr);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        PFQ_TRY(verify_supersets(*t));
+    }
+    *out = t.release();
+    return PFQ_OK;
+}
+
+void put_u64(std::vector<uint8_t> &o, uint64_t v) { o.insert(o.end(), (uint8_t *)&v, (uint8_t *)&v + 8); }
+void put_u32(std::vector<uint8_t> &o, uint32_t v) { o.insert(o.end(), (uint8_t *)&v, (uint8_t *)&v + 4); }
+void put_str(std::vector<uint8_t> &o, const std::string &s) {
+    put_u64(o, s.size());
+    o.insert(o.end(), s.begin(), s.end());
+}
+void encode_node(const pfq_tree &t, int32_t v, std::vector<uint8_t> &o) {
+    const Node &nd = t.nodes[v];
+    for (int32_t c : {nd.left, nd.right}) {
+        o.push_back(c >= 0 ? 1 : 0);
+        if (c >= 0) encode_node(t, c, o);
+    }
+    put_str(o, nd.bf_path);
+    o.push_back(nd.has_tax ? 1 : 0);
+    if (nd.has_tax) put_str(o, nd.tax_id);
+    put_u64(o, nd.mapped_reads);
+}
+
+const char ORDER_NAME[] = "bitvec::order::Lsb0";
+
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+const char *pfq_last_error(void) { return g_err.c_str(); }
+const char *pfq_version(void) { return "libpfq 0.1 (gfx950)"; }
+
+int pfq_tree_open(const char *db_dir, int device, pfq_tree **out) {
+    if (!db_dir || !out) return fail(PFQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    PFQ_TRY(use_device(device));
+    std::unique_ptr<pfq_tree> t(new pfq_tree());
+    t->device = device;
+    std::string dir(db_dir);
+    std::vector<uint8_t> buf;
+    if (!read_file(dir + "/tree.bin", buf))
+        return fail(PFQ_ERR_IO, "cannot read " + dir + "/tree.bin (reference: panic at bloom_tree.rs:375)");
+    Cur c{buf.data(), buf.size()};
+    uint8_t tag = c.u8();
+    if (!c.ok || tag > 1) return fail(PFQ_ERR_FORMAT, "tree.bin: bad Option tag for root");
+    if (tag == 1) PFQ_TRY(parse_node(c, *t, -1, 0, t->root));
+    t->false_pos_rate = c.f32();
+    t->largest_expected_genome = c.u32();
+    t->kmer_size = c.u64();
+    t->seed1 = c.u64();
+    t->seed2 = c.u64();
+    if (!c.ok || c.p != c.n) return fail(PFQ_ERR_FORMAT, "tree.bin: truncated or trailing bytes");
+    // filters keyed by relative path, exactly like the LRU cache key (cache.rs:56-62)
+    std::map<std::string, uint32_t> row_of;
+    for (auto &nd : t->nodes) {
+        auto it = row_of.find(nd.bf_path);
+        if (it == row_of.end()) {
+            nd.filter = (uint32_t)t->filter_paths.size();
+            row_of[nd.bf_path] = nd.filter;
+            t->filter_paths.push_back(nd.bf_path);
+        } else nd.filter = it->second;
+    }
+    bool first = true;
+    std::vector<uint8_t> fb;
+    for (size_t f = 0; f < t->filter_paths.size(); ++f) {
+        const std::string path = dir + "/" + t->filter_paths[f];
+        if (!read_file(path, fb))
+            return fail(PFQ_ERR_IO, "cannot read Bloom filter file " + path + " (reference: panic at bloom_filter.rs:155)");
+        Cur b{fb.data(), fb.size()};
+        std::string order = b.str();
+        uint8_t width = b.u8(), index = b.u8();
+        uint64_t nbits = b.u64(), nwords = b.u64();
+        if (!b.ok || order != ORDER_NAME || width != 64 || index != 0 || nwords != (nbits + 63) / 64)
+            return fail(PFQ_ERR_FORMAT, path + ": not a BitVec<usize, Lsb0> BloomFilter (order/head/length mismatch)");
+        const uint8_t *words = b.take((size_t)nwords * 8);
+        uint32_t nh = b.u32();
+        uint64_t s1 = b.u64(), s2 = b.u64();
+        uint8_t ptag = b.u8();
+        if (b.ok && ptag == 1) (void)b.str();
+        if (!b.ok || ptag > 1 || b.p != b.n) return fail(PFQ_ERR_FORMAT, path + ": truncated or trailing bytes");
+        if (first) {
+            t->nbits = nbits;
+            t->num_hashes = nh;
+            PFQ_TRY(setup_hash_params(*t));
+            HIP_TRY(t->d_bits.ensure(t->filter_paths.size() * t->n_words));
+            first = false;
+        }
+        if (nbits != t->nbits || nh != t->num_hashes)
+            return fail(PFQ_ERR_UNSUPPORTED, path + ": filter size / num_hashes differ from the other nodes");
+        if (s1 != t->seed1 || s2 != t->seed2)
+            return fail(PFQ_ERR_UNSUPPORTED, path + ": hash seeds differ from tree.bin's (node-independent indices need one seed pair)");
+        HIP_TRY(hipMemcpy(t->d_bits.p + f * t->n_words, words, (size_t)nwords * 8, hipMemcpyHostToDevice));
+    }
+    if (t->root >= 0) PFQ_TRY(verify_supersets(*t));
+    *out = t.release();
+    return PFQ_OK;
+}
+
+int pfq_tree_build_balanced(const uint8_t *genomes, const uint64_t *offsets, uint64_t n_genomes, const char *const *tax_ids,
+                            uint64_t kmer_size, uint64_t nbits, uint32_t num_hashes, uint64_t seed1, uint64_t seed2,
+                            float false_pos_rate, uint32_t largest_expected_genome, int device, pfq_tree **out) {
+    if (!out || (n_genomes && (!genomes || !offsets || !tax_ids))) return fail(PFQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    PFQ_TRY(use_device(device));
+    DevBuf<uint8_t> d_g;
+    DevBuf<uint64_t> d_o;
+    uint64_t total = n_genomes ? offsets[n_genomes] : 0;
+    HIP_TRY(d_g.ensure(total + 1));
+    HIP_TRY(d_o.ensure(n_genomes + 1));
+    if (total) HIP_TRY(hipMemcpy(d_g.p, genomes, total, hipMemcpyHostToDevice));
+    if (n_genomes) HIP_TRY(hipMemcpy(d_o.p, offsets, (n_genomes + 1) * 8, hipMemcpyHostToDevice));
+    return build_balanced_common(d_g.p, d_o.p, n_genomes, tax_ids, kmer_size, nbits, num_hashes, seed1, seed2,
+                                 false_pos_rate, largest_expected_genome, device, out);
+}
+
+int pfq_tree_build_balanced_device(const uint8_t *d_genomes, uint64_t genome_len, uint64_t n_genomes,
+                                   const char *const *tax_ids, uint64_t kmer_size, uint64_t nbits, uint32_t num_hashes,
+                                   uint64_t seed1, uint64_t seed2, float false_pos_rate, uint32_t largest_expected_genome,
+                                   int device, pfq_tree **out) {
+    if (!out || (n_genomes && (!d_genomes || !tax_ids))) return fail(PFQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    PFQ_TRY(use_device(device));
+    std::vector<uint64_t> off(n_genomes + 1);
+    for (uint64_t i = 0; i <= n_genomes; ++i) off[i] = i * genome_len;
+    DevBuf<uint64_t> d_o;
+    HIP_TRY(d_o.ensure(n_genomes + 1));
+    HIP_TRY(hipMemcpy(d_o.p, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    return build_balanced_common(d_genomes, d_o.p, n_genomes, tax_ids, kmer_size, nbits, num_hashes, seed1, seed2,
+                                 false_pos_rate, largest_expected_genome, device, out);
+}
+
+int pfq_tree_save(const pfq_tree *tree, const char *db_dir) {
+    if (!tree || !db_dir) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    const pfq_tree &t = *tree;
+    std::string dir(db_dir);
+    std::vector<uint8_t> o;
+    o.push_back(t.root >= 0 ? 1 : 0);
+    if (t.root >= 0) encode_node(t, t.root, o);
+    o.insert(o.end(), (const uint8_t *)&t.false_pos_rate, (const uint8_t *)&t.false_pos_rate + 4);
+    put_u32(o, t.largest_expected_genome);
+    put_u64(o, t.kmer_size);
+    put_u64(o, t.seed1);
+    put_u64(o, t.seed2);
+    {
+        FILE *f = fopen((dir + "/tree.bin").c_str(), "wb");
+        if (!f) return fail(PFQ_ERR_IO, "cannot create " + dir + "/tree.bin: " + strerror(errno));
+        bool ok = fwrite(o.data(), 1, o.size(), f) == o.size();
+        ok = (fclose(f) == 0) && ok;
+        if (!ok) return fail(PFQ_ERR_IO, "short write to tree.bin");
+    }
+    std::vector<uint64_t> words((size_t)t.n_words);
+    for (size_t fi = 0; fi < t.filter_paths.size(); ++fi) {
+        HIP_TRY(hipMemcpy(words.data(), t.d_bits.p + fi * t.n_words, (size_t)t.n_words * 8, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> h;
+        put_str(h, ORDER_NAME);
+        h.push_back(64);
+        h.push_back(0);
+        put_u64(h, t.nbits);
+        put_u64(h, t.n_words);
+        std::vector<uint8_t> tail;
+        put_u32(tail, t.num_hashes);
+        put_u64(tail, t.seed1);
+        put_u64(tail, t.seed2);
+        const std::string path = dir + "/" + t.filter_paths[fi];
+        tail.push_back(1);
+        put_str(tail, path);
+        FILE *f = fopen(path.c_str(), "wb");
+        if (!f) return fail(PFQ_ERR_IO, "cannot create " + path + ": " + strerror(errno));
+        bool ok = fwrite(h.data(), 1, h.size(), f) == h.size();
+        ok = ok && fwrite(words.data(), 8, words.size(), f) == words.size();
+        ok = ok && fwrite(tail.data(), 1, tail.size(), f) == tail.size();
+        ok = (fclose(f) == 0) && ok;
+        if (!ok) return fail(PFQ_ERR_IO, "short write to " + path);
+    }
+    return PFQ_OK;
+}
+
+int pfq_tree_info(const pfq_tree *tree, pfq_info *out) {
+    if (!tree || !out) return fail(PFQ_ERR_ARG, "null argument");
+    const pfq_tree &t = *tree;
+    out->kmer_size = t.kmer_size;
+    out->nbits = t.nbits;
+    out->num_hashes = t.num_hashes;
+    out->largest_expected_genome = t.largest_expected_genome;
+    out->false_pos_rate = t.false_pos_rate;
+    out->superset_verified = t.superset_all ? 1 : 0;
+    out->seed1 = t.seed1;
+    out->seed2 = t.seed2;
+    out->n_nodes = t.nodes.size();
+    out->n_leaves = leaves_dfs(t).size();
+    out->n_filters = t.filter_paths.size();
+    out->device_bytes = t.d_bits.bytes() + t.d_S.bytes() + t.d_pairs.bytes() + t.d_sorted.bytes() + t.d_fail.bytes() +
+                        t.d_hit_pairs.bytes() + t.d_seq.bytes() + t.d_off.bytes();
+    return PFQ_OK;
+}
+
+int pfq_tree_prune(pfq_tree *tree, uint64_t search_depth) {
+    if (!tree) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    pfq_tree &t = *tree;
+    if (t.root < 0) return fail(PFQ_ERR_STATE, "prune_tree on an empty tree (reference: unwrap panic, bloom_tree.rs:310)");
+    PFQ_TRY(sync_counts_to_nodes(t));
+    relink(t);
+    for (auto &nd : t.nodes)
+        if (nd.depth >= search_depth) nd.left = nd.right = -1;  // bloom_tree.rs:322-325
+    // nodes below the cut are unreachable now; they keep their slots (and filters) but never appear as leaves
+    t.layout_valid = false;
+    return PFQ_OK;
+}
+
+void pfq_tree_close(pfq_tree *tree) {
+    if (!tree) return;
+    (void)hipSetDevice(tree->device);
+    (void)hipDeviceSynchronize();
+    delete tree;
+}
+
+int pfq_query_batch_device(pfq_tree *tree, const uint8_t *d_seq, const uint64_t *d_offsets, uint64_t n_reads,
+                           uint64_t total_bytes, float threshold, uint32_t flags, void *stream, pfq_hits *hits) {
+    (void)total_bytes;
+    if (!tree || (n_reads && (!d_seq || !d_offsets))) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    return query_device(*tree, d_seq, d_offsets, n_reads, threshold, flags, (hipStream_t)stream, hits);
+}
+
+int pfq_query_batch(pfq_tree *tree, const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads, float threshold,
+                    uint32_t flags, pfq_hits *hits) {
+    if (!tree || (n_reads && (!seq || !offsets))) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    pfq_tree &t = *tree;
+    uint64_t total = n_reads ? offsets[n_reads] : 0;
+    HIP_TRY(t.d_seq.ensure(total + 16));
+    HIP_TRY(t.d_off.ensure(n_reads + 1));
+    if (total) HIP_TRY(hipMemcpy(t.d_seq.p, seq, total, hipMemcpyHostToDevice));
+    if (n_reads) HIP_TRY(hipMemcpy(t.d_off.p, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice));
+    PFQ_TRY(query_device(t, t.d_seq.p, t.d_off.p, n_reads, threshold, flags, nullptr, hits));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return PFQ_OK;
+}
+
+int pfq_leaf_counts(pfq_tree *tree, const char *const **tax_ids, const uint64_t **counts, uint64_t *n_leaves) {
+    if (!tree || !n_leaves) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    pfq_tree &t = *tree;
+    PFQ_TRY(build_layout(t));
+    PFQ_TRY(sync_counts_to_nodes(t));
+    t.out_tax.clear();
+    t.out_counts.clear();
+    for (int32_t v : t.leaves) {
+        t.out_tax.push_back(t.nodes[v].tax_id);
+        t.out_counts.push_back(t.nodes[v].mapped_reads);
+    }
+    t.out_tax_ptr.clear();
+    for (auto &s : t.out_tax) t.out_tax_ptr.push_back(s.c_str());
+    if (tax_ids) *tax_ids = t.out_tax_ptr.data();
+    if (counts) *counts = t.out_counts.data();
+    *n_leaves = t.leaves.size();
+    return PFQ_OK;
+}
+
+int pfq_save_leaf_counts(pfq_tree *tree, const char *csv_path) {
+    if (!tree || !csv_path) return fail(PFQ_ERR_ARG, "null argument");
+    const char *const *ids = nullptr;
+    const uint64_t *cnt = nullptr;
+    uint64_t n = 0;
+    PFQ_TRY(pfq_leaf_counts(tree, &ids, &cnt, &n));
+    FILE *f = fopen(csv_path, "wb");
+    if (!f) return fail(PFQ_ERR_IO, std::string("cannot create ") + csv_path + ": " + strerror(errno));
+    for (uint64_t i = 0; i < n; ++i)
+        if (cnt[i] > 0) fprintf(f, "%s,%llu\n", ids[i], (unsigned long long)cnt[i]);  // query.rs:177-182
+    if (fclose(f) != 0) return fail(PFQ_ERR_IO, "short write to CLASSIFICATION.csv");
+    return PFQ_OK;
+}
+
+int pfq_leaf_counts_export(pfq_tree *tree, uint64_t *d_dst, void *stream) {
+    if (!tree || !d_dst) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    PFQ_TRY(build_layout(*tree));
+    if (!tree->leaves.empty())
+        HIP_TRY(hipMemcpyAsync(d_dst, tree->d_counts.p, tree->leaves.size() * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PFQ_OK;
+}
+int pfq_leaf_counts_import(pfq_tree *tree, const uint64_t *d_src, void *stream) {
+    if (!tree || !d_src) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    PFQ_TRY(build_layout(*tree));
+    if (!tree->leaves.empty())
+        HIP_TRY(hipMemcpyAsync(tree->d_counts.p, d_src, tree->leaves.size() * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PFQ_OK;
+}
+int pfq_leaf_counts_reset(pfq_tree *tree) {
+    if (!tree) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    PFQ_TRY(build_layout(*tree));
+    HIP_TRY(hipDeviceSynchronize());
+    if (!tree->leaves.empty()) HIP_TRY(hipMemset(tree->d_counts.p, 0, tree->leaves.size() * 8));
+    for (auto &nd : tree->nodes) nd.mapped_reads = 0;
+    return PFQ_OK;
+}
+
+int pfq_last_stats(pfq_tree *tree, pfq_stats *out) {
+    if (!tree || !out) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    pfq_tree &t = *tree;
+    memset(out, 0, sizeof *out);
+    if (!t.d_stats.p) return PFQ_OK;
+    HIP_TRY(hipStreamSynchronize(t.last_stream));
+    unsigned long long h[pfq::ST_N];
+    HIP_TRY(hipMemcpy(h, t.d_stats.p, sizeof h, hipMemcpyDeviceToHost));
+    out->n_reads = t.last_n_reads;
+    out->n_candidates = h[pfq::ST_CANDIDATES];
+    out->n_hits = h[pfq::ST_HITS];
+    out->n_allhit_reads = h[pfq::ST_ALLHIT];
+    out->algorithmic_bytes = h[pfq::ST_ALG_BYTES];
+    out->path = t.last_path;
+    out->n_slices = t.last_slices;
+    return PFQ_OK;
+}
+int pfq_profile_begin(pfq_tree *tree, uint32_t max_calls) {
+    if (!tree) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    pfq_tree &t = *tree;
+    while (t.prof_ev.size() < 5 * (size_t)max_calls) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        t.prof_ev.push_back(e);
+    }
+    t.prof_cap = max_calls;
+    t.prof_used = 0;
+    t.prof_bucketed.assign(max_calls, 0);
+    return PFQ_OK;
+}
+int pfq_profile_end(pfq_tree *tree, pfq_profile *out) {
+    if (!tree || !out) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    pfq_tree &t = *tree;
+    memset(out, 0, sizeof *out);
+    HIP_TRY(hipStreamSynchronize(t.last_stream));
+    for (size_t c = 0; c < t.prof_used; ++c) {
+        hipEvent_t *ev = &t.prof_ev[5 * c];
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        out->classify_ms += ms;
+        if (t.prof_bucketed[c]) {
+            HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2]));
+            out->bucket_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3]));
+            out->verify_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4]));
+            out->finalize_ms += ms;
+        }
+    }
+    out->calls = t.prof_used;
+    t.prof_cap = t.prof_used = 0;
+    return PFQ_OK;
+}
+int pfq_set_path(pfq_tree *tree, int path) {
+    if (!tree || path < -1 || path > 1) return fail(PFQ_ERR_ARG, "bad argument");
+    tree->force_path = path;
+    return PFQ_OK;
+}
+
+int pfq_debug_kmer_indices(pfq_tree *tree, const uint8_t *seq, uint64_t len, uint64_t *out_idx, uint64_t *n_kmers) {
+    if (!tree || !n_kmers || (len && !seq)) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    pfq_tree &t = *tree;
+    uint64_t n = (t.kmer_size >= 1 && len >= t.kmer_size) ? len - t.kmer_size + 1 : 0;
+    *n_kmers = n;
+    if (!n || !out_idx) return PFQ_OK;
+    DevBuf<uint8_t> d_s;
+    DevBuf<uint64_t> d_o;
+    HIP_TRY(d_s.ensure(len + 16));
+    HIP_TRY(d_o.ensure(n * t.num_hashes));
+    HIP_TRY(hipMemcpy(d_s.p, seq, len, hipMemcpyHostToDevice));
+    pfq::launch_debug_indices(t.hp, d_s.p, len, d_o.p, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out_idx, d_o.p, n * t.num_hashes * 8, hipMemcpyDeviceToHost));
+    return PFQ_OK;
+}
+
+int pfq_debug_node_filter(pfq_tree *tree, uint64_t node, uint64_t *out_words, uint64_t n_words) {
+    if (!tree || !out_words) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    if (node >= tree->nodes.size() || n_words != tree->n_words) return fail(PFQ_ERR_ARG, "node / n_words out of range");
+    HIP_TRY(hipMemcpy(out_words, tree->d_bits.p + (uint64_t)tree->nodes[node].filter * tree->n_words, n_words * 8,
+                      hipMemcpyDeviceToHost));
+    return PFQ_OK;
+}
+
+int pfq_synth_genomes_device(uint8_t *d_out, uint64_t n_genomes, uint64_t genome_len, uint64_t seed_base, void *stream) {
+    if (!d_out) return fail(PFQ_ERR_ARG, "null argument");
+    pfq::launch_synth_genomes(d_out, n_genomes, genome_len, seed_base, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return PFQ_OK;
+}
+int pfq_synth_reads_device(uint8_t *d_out, uint64_t first_read, uint64_t n_reads, uint64_t read_len, const uint8_t *d_genomes,
+                           uint64_t genome_len, uint64_t n_genomes, uint64_t seed, void *stream) {
+    if (!d_out) return fail(PFQ_ERR_ARG, "null argument");
+    pfq::launch_synth_reads(d_out, first_read, n_reads, read_len, d_genomes, genome_len, n_genomes, seed, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return PFQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,551 @@
+// pfq_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) of the classification path.
+//
+//   k_classify   K1+K2+K3 in one launch: one wave per read.  The frontier over the leaf level of the SBT is a
+//                bitmask spread over the lanes (one dword = 32 leaves per lane); each probe of the sliced matrix S
+//                ANDs one 128-B line (the same Bloom bit for 1024 leaves) into it, `__ballot` tests it for
+//                emptiness (subtree/leaf pruning), and surviving leaves get the full certificate of
+//                query_passes (query.rs:38-49): lanes = k-mers, `__ballot` of "all probed bits set",
+//                `__popcll` accumulate, compare with need.  DEFER variant hands survivors to the bucketed pass.
+//   k_verify     the certificate for survivors bucketed by leaf: every XCD keeps one slice of the current
+//                leaf's node-major filter hot in its own L2 and checks only the probes that fall in its slice.
+//   k_insert / k_union / k_superset / k_transpose   database construction on the device.
+//
+// Reference semantics: query.rs:38-158, bloom_filter.rs:312-332, hash_iter.rs:13-45, file_parser.rs:114-148.
+#include "pfq_kernels.h"
+
+namespace pfq {
+
+__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((31u << 11) | 20u) & 0xFu; }
+
+constexpr uint32_t SCREEN_ROUNDS = 2;  // row loads in flight per lane and probe in the theta=1 screen
+constexpr uint32_t NPLANES = 16;       // vertical-counter planes of the theta<1 screen (k-mers per read < 65536)
+
+struct ReadCtx {
+    const uint8_t *read;
+    uint64_t n;         // k-mers
+    uint64_t need;      // ceil_f32(threshold * n)
+    uint64_t maxmiss;   // n - need
+};
+
+// ---- K2: certificate of one column of S --------------------------------------------------------------------------
+// Returns whether #k-mers with all num_hashes bits set in column `col` >= need (query_passes, query.rs:38-49).
+__device__ __forceinline__ bool verify_column(BlockLds &lds, uint32_t wave, const QueryArgs &a, const ReadCtx &rc,
+                                              uint32_t col) {
+    const uint32_t lane = lane_id();
+    const uint32_t cw = col >> 5, cb = col & 31u;
+    uint64_t hits = 0, seen = 0;
+    for (uint64_t base = 0; base < rc.n; base += WIN_KMERS) {
+        uint32_t cnt = (uint32_t)((rc.n - base) < WIN_KMERS ? (rc.n - base) : WIN_KMERS);
+        stage_window(lds, wave, rc.read, base, cnt, a.hp.k);
+        bool valid = lane < cnt;
+        uint64_t h1, h2;
+        kmer_hashes(lds, wave, lane, cnt, valid, a.hp, h1, h2);
+        ProbeIter it;
+        it.init(h1, h2, a.hp);
+        uint32_t ok = 1;
+#pragma unroll 5
+        for (uint32_t i = 0; i < a.hp.num_hashes; ++i) {
+            uint32_t idx = it.get(i, a.hp);
+            uint32_t v = valid ? a.S[(uint64_t)idx * a.rw + cw] : 0u;
+            ok &= (v >> cb);
+        }
+        uint64_t b = ballot64(valid && (ok & 1u));
+        hits += (uint64_t)__popcll(b);
+        seen += cnt;
+        if (hits >= rc.need) return true;
+        if (seen - hits > rc.maxmiss) return false;
+    }
+    return hits >= rc.need;
+}
+
+// ---- K3 (theta == 1): AND-frontier over the leaf level ---------------------------------------------------------------
+// Probes 0 and 1 of the first SCREEN_ROUNDS*slots k-mers: every row is one line of S.  A leaf survives only if all
+// probed bits are set (necessary for passing at need == n).
+__device__ __forceinline__ uint32_t screen_all(BlockLds &lds, uint32_t wave, const QueryArgs &a, const ReadCtx &rc,
+                                               uint32_t colmask) {
+    const uint32_t lane = lane_id(), rw = a.rw, slots = 64u >> a.rw_log2;
+    const uint32_t word = lane & (rw - 1u), slot = lane >> a.rw_log2;
+    uint32_t cnt = (uint32_t)(rc.n < WIN_KMERS ? rc.n : WIN_KMERS);
+    stage_window(lds, wave, rc.read, 0, cnt, a.hp.k);
+    uint64_t h1, h2;
+    kmer_hashes(lds, wave, lane, cnt, lane < cnt, a.hp, h1, h2);
+    uint32_t i0 = mod_nbits(h1, a.hp), i1 = mod_nbits(h2, a.hp);
+    uint32_t v0[SCREEN_ROUNDS], v1[SCREEN_ROUNDS];
+#pragma unroll
+    for (uint32_t j = 0; j < SCREEN_ROUNDS; ++j) {
+        uint32_t kk = j * slots + slot;
+        bool valid = kk < cnt;
+        uint32_t src = valid ? kk : 0u;
+        uint32_t r0 = (uint32_t)__shfl((int)i0, (int)src), r1 = (uint32_t)__shfl((int)i1, (int)src);
+        v0[j] = valid ? a.S[(uint64_t)r0 * rw + word] : ~0u;
+        v1[j] = (valid && a.hp.num_hashes > 1) ? a.S[(uint64_t)r1 * rw + word] : ~0u;
+    }
+    uint32_t live = colmask;
+#pragma unroll
+    for (uint32_t j = 0; j < SCREEN_ROUNDS; ++j) live &= v0[j] & v1[j];
+    for (uint32_t s = rw; s < 64u; s <<= 1) live &= (uint32_t)__shfl_xor((int)live, (int)s);
+    return live;
+}
+
+// ---- K3 (theta < 1): miss-counting frontier ---------------------------------------------------------------------------
+// A k-mer is a definite miss for a leaf if its first probed bit is 0.  Per-leaf miss counts are kept as
+// bit-sliced ("vertical") counters, one plane per register; a leaf leaves the frontier once misses > n - need.
+__device__ __forceinline__ void vc_add(uint32_t (&c)[NPLANES], uint32_t m) {
+#pragma unroll
+    for (uint32_t p = 0; p < NPLANES; ++p) {
+        uint32_t t = c[p] & m;
+        c[p] ^= m;
+        m = t;
+    }
+}
+__device__ __forceinline__ uint32_t screen_counts(BlockLds &lds, uint32_t wave, const QueryArgs &a, const ReadCtx &rc,
+                                                  uint32_t colmask) {
+    const uint32_t lane = lane_id(), rw = a.rw, slots = 64u >> a.rw_log2;
+    const uint32_t word = lane & (rw - 1u), slot = lane >> a.rw_log2;
+    if (rc.n >= (1ull << NPLANES)) return colmask;  // counters too narrow: no screening, certify every leaf
+    uint32_t c[NPLANES];
+#pragma unroll
+    for (uint32_t p = 0; p < NPLANES; ++p) c[p] = 0;
+    uint32_t live = colmask;
+    for (uint64_t base = 0; base < rc.n; base += WIN_KMERS) {
+        uint32_t cnt = (uint32_t)((rc.n - base) < WIN_KMERS ? (rc.n - base) : WIN_KMERS);
+        stage_window(lds, wave, rc.read, base, cnt, a.hp.k);
+        uint64_t h1, h2;
+        kmer_hashes(lds, wave, lane, cnt, lane < cnt, a.hp, h1, h2);
+        uint32_t i0 = mod_nbits(h1, a.hp);
+        for (uint32_t t = 0; t < cnt; t += slots) {
+            uint32_t kk = t + slot;
+            bool valid = kk < cnt;
+            uint32_t r0 = (uint32_t)__shfl((int)i0, (int)(valid ? kk : 0u));
+            uint32_t v = valid ? a.S[(uint64_t)r0 * rw + word] : ~0u;
+            vc_add(c, ~v & colmask);
+        }
+        // total over the slots (ripple-carry add of vertical counters), then misses > maxmiss ?
+        uint32_t tot[NPLANES];
+#pragma unroll
+        for (uint32_t p = 0; p < NPLANES; ++p) tot[p] = c[p];
+        for (uint32_t s = rw; s < 64u; s <<= 1) {
+            uint32_t carry = 0;
+#pragma unroll
+            for (uint32_t p = 0; p < NPLANES; ++p) {
+                uint32_t o = (uint32_t)__shfl_xor((int)tot[p], (int)s);
+                uint32_t x = tot[p] ^ o;
+                uint32_t sum = x ^ carry;
+                carry = (tot[p] & o) | (carry & x);
+                tot[p] = sum;
+            }
+        }
+        uint32_t gt = 0, eq = ~0u;
+#pragma unroll
+        for (int p = (int)NPLANES - 1; p >= 0; --p) {
+            uint32_t mb = ((rc.maxmiss >> p) & 1ull) ? ~0u : 0u;
+            gt |= eq & tot[p] & ~mb;
+            eq &= ~(tot[p] ^ mb);
+        }
+        live = colmask & ~gt;
+        if (ballot64(live != 0) == 0) return 0;
+    }
+    return live;
+}
+
+// ---- the classification kernel ---------------------------------------------------------------------------------------
+template <bool DEFER, bool COUNTS>
+__global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
+    __shared__ BlockLds lds;
+    fill_complement(lds.comp);
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t gw = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave, nw = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    const uint32_t rw = a.rw;
+    const uint32_t word = lane & (rw - 1u), slot = lane >> a.rw_log2;
+    uint32_t colmask = 0;  // leaf columns of my dword
+    if (word * 32u < a.n_leaves) colmask = (a.n_leaves - word * 32u >= 32u) ? ~0u : ((1u << (a.n_leaves - word * 32u)) - 1u);
+    unsigned long long st_cand = 0, st_hits = 0, st_all = 0, st_bytes = 0, st_def = 0;
+
+    for (uint64_t r = gw; r < a.n_reads; r += nw) {
+        const uint64_t o0 = a.off[r], L = a.off[r + 1] - o0;
+        ReadCtx rc;
+        rc.read = a.seq + o0;
+        rc.n = (L >= a.hp.k) ? (L - a.hp.k + 1) : 0;  // get_kmers, file_parser.rs:135-138
+        rc.need = need_kmers(a.threshold, rc.n);       // query.rs:48
+        st_bytes += L;
+        if (rc.need == 0) {  // 0 >= 0 at every node: the read reaches and counts at every leaf
+            ++st_all;
+            if (a.allhit_flag && lane == 0) a.allhit_flag[r] = 1;
+            continue;
+        }
+        if (rc.need > rc.n) continue;  // cannot pass any node
+        rc.maxmiss = rc.n - rc.need;
+
+        // The AND-frontier is only valid when no miss is tolerated; (n as f32) rounds for n >= 2^24, so even at
+        // theta == 1 a read can have maxmiss > 0: such reads are certified against every leaf instead.
+        uint32_t live = COUNTS ? screen_counts(lds, wave, a, rc, colmask)
+                               : (rc.maxmiss == 0 ? screen_all(lds, wave, a, rc, colmask) : colmask);
+
+        while (true) {
+            uint64_t b = ballot64(live != 0 && slot == 0);
+            if (!b) break;
+            int src = __ffsll((unsigned long long)b) - 1;
+            uint32_t wv = bcast_u32(live, src);
+            uint32_t bit = (uint32_t)__ffs((int)wv) - 1u;
+            uint32_t col = (uint32_t)src * 32u + bit;
+            if ((int)lane == src) live &= ~(1u << bit);
+            ++st_cand;
+            if (DEFER) {
+                uint32_t pushed = 0;
+                if (lane == 0) {
+                    unsigned long long pos = atomicAdd(a.pair_cursor, 1ull);
+                    if (pos < a.pair_cap) {
+                        a.pairs[pos] = make_uint2((uint32_t)r, col);
+                        atomicAdd(&a.bucket_cnt[col], 1u);
+                        pushed = 1;
+                    }
+                }
+                pushed = bcast_u32(pushed, 0);
+                if (pushed) { ++st_def; continue; }
+            }
+            bool pass = verify_column(lds, wave, a, rc, col);
+            // ancestors that are not provably supersets must pass too (query.rs:119-141 visits children only with
+            // reads that passed the parent)
+            for (uint32_t g = a.guard_off[col]; pass && g < a.guard_off[col + 1]; ++g)
+                pass = verify_column(lds, wave, a, rc, a.guard_col[g]);
+            if (pass) {
+                ++st_hits;
+                st_bytes += rc.need * a.hp.num_hashes * 32ull;
+                if (lane == 0) {
+                    atomicAdd(&a.counts[col], 1ull);
+                    if (a.hit_pairs) {
+                        unsigned long long pos = atomicAdd(a.hit_cursor, 1ull);
+                        if (pos < a.hit_cap) a.hit_pairs[pos] = make_uint2((uint32_t)r, col);
+                    }
+                }
+            }
+        }
+    }
+    // reads that pass every node (need == 0) count at every leaf (query.rs:143 reached through every path)
+    if (st_all)
+        for (uint32_t c = lane; c < a.n_leaves; c += 64) atomicAdd(&a.counts[c], st_all);
+    if (lane == 0) {
+        if (st_cand) atomicAdd(&a.stats[ST_CANDIDATES], st_cand);
+        if (st_hits) atomicAdd(&a.stats[ST_HITS], st_hits);
+        if (st_all) atomicAdd(&a.stats[ST_ALLHIT], st_all);
+        if (st_bytes) atomicAdd(&a.stats[ST_ALG_BYTES], st_bytes);
+        if (st_def) atomicAdd(&a.stats[ST_DEFERRED], st_def);
+    }
+}
+
+void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int blocks, hipStream_t st) {
+    dim3 g(blocks), b(256);
+    if (defer) {
+        if (counts_mode) hipLaunchKernelGGL((k_classify<true, true>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_classify<true, false>), g, b, 0, st, a);
+    } else {
+        if (counts_mode) hipLaunchKernelGGL((k_classify<false, true>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_classify<false, false>), g, b, 0, st, a);
+    }
+}
+
+// ---- bucketing of deferred (read, leaf) pairs by leaf --------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_bucket_scan(const uint32_t *cnt, uint32_t *off, uint32_t *cur, uint32_t n) {
+    // one wave; n <= 2048 leaves: lane l owns entries [l*per, (l+1)*per)
+    uint32_t lane = lane_id(), per = (n + 63u) / 64u;
+    uint32_t lo = lane * per, hi = lo + per < n ? lo + per : n;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += cnt[i];
+    uint32_t incl = s;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += t;
+    }
+    uint32_t run = incl - s;
+    for (uint32_t i = lo; i < hi; ++i) {
+        off[i] = run;
+        cur[i] = 0;
+        run += cnt[i];
+    }
+    if (lane == 63) off[n] = incl;
+}
+void launch_bucket_scan(const uint32_t *bucket_cnt, uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(64), 0, st, bucket_cnt, bucket_off, bucket_cur, n);
+}
+
+__global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr,
+                                                        uint64_t pair_cap, const uint32_t *off, uint32_t *cur, uint2 *sorted) {
+    uint64_t n = *n_pairs_ptr;
+    if (n > pair_cap) n = pair_cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint2 p = pairs[i];
+        uint32_t pos = atomicAdd(&cur[p.y], 1u);
+        sorted[off[p.y] + pos] = p;
+    }
+}
+void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
+                           const uint32_t *bucket_off, uint32_t *bucket_cur, uint2 *sorted, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, pairs, n_pairs_ptr, pair_cap, bucket_off, bucket_cur, sorted);
+}
+
+// ---- K2 for bucketed survivors: L2-resident filter slices ------------------------------------------------------------
+// Work item = `chunk` consecutive sorted pairs x one slice of the filter's bit range.  A wave prefers the slice
+// its XCD is responsible for (XCC_ID % n_slices), so the 32 CUs of an XCD keep gathering from the same <= 2.5 MB
+// of the current leaf's filter, which therefore stays in that XCD's 4 MiB L2 (speed only; any wave may take any
+// item).  theta == 1 only: every probed bit must be set, so slices are independent and any miss fails the pair.
+__global__ void __launch_bounds__(256) k_verify(VerifyArgs a) {
+    __shared__ BlockLds lds;
+    fill_complement(lds.comp);
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint64_t n_pairs = *a.n_pairs_ptr;
+    if (n_pairs > a.pair_cap) n_pairs = a.pair_cap;
+    const uint64_t n_items = (n_pairs + a.chunk - 1) / a.chunk;
+    const uint32_t home = xcc_id() % a.n_slices;
+    for (uint32_t att = 0; att < a.n_slices; ++att) {
+        const uint32_t s = (home + att) % a.n_slices;
+        const uint32_t lo = s * a.slice_bits;
+        while (true) {
+            uint32_t item = 0;
+            if (lane == 0) item = atomicAdd(&a.queue[s], 1u);
+            item = bcast_u32(item, 0);
+            if (item >= n_items) break;
+            uint64_t e0 = (uint64_t)item * a.chunk, e1 = e0 + a.chunk < n_pairs ? e0 + a.chunk : n_pairs;
+            for (uint64_t e = e0; e < e1; ++e) {
+                const uint2 p = a.sorted[e];
+                const uint64_t o0 = a.off[p.x], L = a.off[p.x + 1] - o0;
+                const uint64_t n = L - a.hp.k + 1;  // candidates always have n >= 1
+                const uint8_t *read = a.seq + o0;
+                const uint32_t *bm = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)a.col_row[p.y] * a.n_words);
+                bool miss = false;
+                for (uint64_t base = 0; base < n; base += WIN_KMERS) {
+                    uint32_t cnt = (uint32_t)((n - base) < WIN_KMERS ? (n - base) : WIN_KMERS);
+                    stage_window(lds, wave, read, base, cnt, a.hp.k);
+                    bool valid = lane < cnt;
+                    uint64_t h1, h2;
+                    kmer_hashes(lds, wave, lane, cnt, valid, a.hp, h1, h2);
+                    ProbeIter it;
+                    it.init(h1, h2, a.hp);
+                    uint32_t ok = 1;
+#pragma unroll 5
+                    for (uint32_t i = 0; i < a.hp.num_hashes; ++i) {
+                        uint32_t idx = it.get(i, a.hp);
+                        bool in = valid && (idx - lo) < a.slice_bits;
+                        uint32_t v = in ? bm[idx >> 5] : ~0u;
+                        ok &= (v >> (idx & 31u));
+                    }
+                    miss = !(ok & 1u);
+                    if (ballot64(miss)) { miss = true; break; }
+                }
+                if (miss && lane == 0) a.fail[e] = 1u;
+            }
+        }
+    }
+}
+void launch_verify(const VerifyArgs &a, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_verify, dim3(blocks), dim3(256), 0, st, a);
+}
+
+// One block per leaf bucket: pairs that no slice failed are hits (mapped_reads += |pass|, query.rs:143).
+__global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
+    __shared__ unsigned long long s_cnt, s_bytes;
+    for (uint32_t c = blockIdx.x; c < a.n_leaves; c += gridDim.x) {
+        if (threadIdx.x == 0) { s_cnt = 0; s_bytes = 0; }
+        __syncthreads();
+        unsigned long long cnt = 0, bytes = 0;
+        for (uint32_t e = a.bucket_off[c] + threadIdx.x; e < a.bucket_off[c + 1]; e += blockDim.x) {
+            if (!a.fail[e]) {
+                uint2 p = a.sorted[e];
+                uint64_t L = a.off[p.x + 1] - a.off[p.x];
+                ++cnt;
+                bytes += (L - a.hp.k + 1) * a.hp.num_hashes * 32ull;
+                if (a.hit_pairs) {
+                    unsigned long long pos = atomicAdd(a.hit_cursor, 1ull);
+                    if (pos < a.hit_cap) a.hit_pairs[pos] = p;
+                }
+            }
+        }
+        for (int d = 32; d > 0; d >>= 1) {
+            cnt += __shfl_down(cnt, d);
+            bytes += __shfl_down(bytes, d);
+        }
+        if (lane_id() == 0 && cnt) { atomicAdd(&s_cnt, cnt); atomicAdd(&s_bytes, bytes); }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt) {
+            atomicAdd(&a.counts[c], s_cnt);
+            atomicAdd(&a.stats[ST_HITS], s_cnt);
+            atomicAdd(&a.stats[ST_ALG_BYTES], s_bytes);
+        }
+        __syncthreads();
+    }
+}
+void launch_finalize(const FinalizeArgs &a, hipStream_t st) {
+    uint32_t blocks = a.n_leaves < 2048u ? a.n_leaves : 2048u;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, st, a);
+}
+
+// ---- database construction --------------------------------------------------------------------------------------------
+// Leaf filters: insert every canonical k-mer of genome g (what init_leaf_node does serially, bloom_tree.rs:154-168;
+// bits as ASMS::insert sets them, bloom_filter.rs:291-307).
+__global__ void __launch_bounds__(256) k_insert(HashParams hp, const uint8_t *genomes, const uint64_t *goff,
+                                                const uint32_t *leaf_row, uint64_t *bits, uint64_t n_words) {
+    __shared__ BlockLds lds;
+    fill_complement(lds.comp);
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, g = blockIdx.y;
+    const uint64_t o0 = goff[g], L = goff[g + 1] - o0;
+    const uint64_t n = (L >= hp.k) ? (L - hp.k + 1) : 0;
+    unsigned long long *row = reinterpret_cast<unsigned long long *>(bits + (uint64_t)leaf_row[g] * n_words);
+    const uint64_t wid = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave, stride = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (uint64_t base = wid * WIN_KMERS; base < n; base += stride * WIN_KMERS) {
+        uint32_t cnt = (uint32_t)((n - base) < WIN_KMERS ? (n - base) : WIN_KMERS);
+        stage_window(lds, wave, genomes + o0, base, cnt, hp.k);
+        bool valid = lane < cnt;
+        uint64_t h1, h2;
+        kmer_hashes(lds, wave, lane, cnt, valid, hp, h1, h2);
+        ProbeIter it;
+        it.init(h1, h2, hp);
+        for (uint32_t i = 0; i < hp.num_hashes; ++i) {
+            uint32_t idx = it.get(i, hp);
+            if (valid) atomicOr(&row[idx >> 6], 1ull << (idx & 63u));
+        }
+    }
+}
+void launch_insert(const HashParams &hp, const uint8_t *d_genomes, const uint64_t *d_goff, uint32_t n_genomes,
+                   const uint32_t *d_leaf_row, uint64_t *bits, uint64_t n_words, hipStream_t st) {
+    if (!n_genomes) return;
+    hipLaunchKernelGGL(k_insert, dim3(64, n_genomes), dim3(256), 0, st, hp, d_genomes, d_goff, d_leaf_row, bits, n_words);
+}
+
+// Internal filter = OR of its children (node_union, bloom_tree.rs:238-239 / bloom_filter.rs:275-278).
+__global__ void __launch_bounds__(256) k_union(uint64_t *bits, uint64_t n_words, const uint32_t *triples) {
+    const uint32_t d = triples[3 * blockIdx.y], x = triples[3 * blockIdx.y + 1], y = triples[3 * blockIdx.y + 2];
+    uint64_t *dst = bits + (uint64_t)d * n_words;
+    const uint64_t *a = bits + (uint64_t)x * n_words, *b = bits + (uint64_t)(y == 0xffffffffu ? x : y) * n_words;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x)
+        dst[i] = a[i] | b[i];
+}
+void launch_union(uint64_t *bits, uint64_t n_words, const uint32_t *d_triples, uint32_t n_triples, hipStream_t st) {
+    if (!n_triples) return;
+    uint32_t bx = (uint32_t)((n_words + 255) / 256);
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(k_union, dim3(bx, n_triples), dim3(256), 0, st, bits, n_words, d_triples);
+}
+
+// parent ⊇ child per edge (the invariant that makes the tree walk pure pruning).
+__global__ void __launch_bounds__(256) k_superset(const uint64_t *bits, uint64_t n_words, const uint32_t *edges, uint32_t *fail) {
+    const uint64_t *p = bits + (uint64_t)edges[2 * blockIdx.y] * n_words, *c = bits + (uint64_t)edges[2 * blockIdx.y + 1] * n_words;
+    uint64_t bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x)
+        bad |= c[i] & ~p[i];
+    if (ballot64(bad != 0) && lane_id() == 0) atomicOr(&fail[blockIdx.y], 1u);
+}
+void launch_superset(const uint64_t *bits, uint64_t n_words, const uint32_t *d_edges, uint32_t n_edges, uint32_t *d_fail, hipStream_t st) {
+    if (!n_edges) return;
+    uint32_t bx = (uint32_t)((n_words + 255) / 256);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(k_superset, dim3(bx, n_edges), dim3(256), 0, st, bits, n_words, d_edges, d_fail);
+}
+
+// node-major -> sliced: wave = 64 columns x 4 consecutive u64 words; `__ballot` transposes 64 columns x 1 bit.
+__global__ void __launch_bounds__(256) k_transpose(const uint64_t *bits, uint64_t n_words, const uint32_t *col_row,
+                                                   uint32_t n_cols, uint32_t *S, uint32_t rw) {
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, cg = blockIdx.y;
+    const uint32_t col = cg * 64u + lane;
+    const bool has = col < n_cols;
+    const uint64_t *src = bits + (uint64_t)(has ? col_row[col] : 0u) * n_words;
+    const uint64_t n_groups = (n_words + 3) / 4;
+    for (uint64_t grp = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; grp < n_groups; grp += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
+        uint64_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint64_t wi = grp * 4 + j;
+            v[j] = (has && wi < n_words) ? src[wi] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint64_t wi = grp * 4 + j;
+            if (wi >= n_words) break;
+            uint64_t keep = 0;
+            for (uint32_t b = 0; b < 64; ++b) {
+                uint64_t m = ballot64((v[j] >> b) & 1ull);
+                if (lane == b) keep = m;
+            }
+            uint32_t *dst = S + (wi * 64 + lane) * (uint64_t)rw + cg * 2u;
+            if (cg * 2u < rw) dst[0] = (uint32_t)keep;
+            if (cg * 2u + 1u < rw) dst[1] = (uint32_t)(keep >> 32);
+        }
+    }
+}
+void launch_transpose(const uint64_t *bits, uint64_t n_words, const uint32_t *d_col_row, uint32_t n_cols, uint32_t *S,
+                      uint32_t rw, hipStream_t st) {
+    if (!n_cols) return;
+    uint32_t groups = (n_cols + 63) / 64;
+    uint64_t bx = (n_words + 15) / 16;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(k_transpose, dim3((uint32_t)bx, groups), dim3(256), 0, st, bits, n_words, d_col_row, n_cols, S, rw);
+}
+
+// ---- test / bench helpers ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_debug_indices(HashParams hp, const uint8_t *seq, uint64_t len, uint64_t *out) {
+    __shared__ BlockLds lds;
+    fill_complement(lds.comp);
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t n = (len >= hp.k) ? (len - hp.k + 1) : 0;
+    const uint64_t wid = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave, stride = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (uint64_t base = wid * WIN_KMERS; base < n; base += stride * WIN_KMERS) {
+        uint32_t cnt = (uint32_t)((n - base) < WIN_KMERS ? (n - base) : WIN_KMERS);
+        stage_window(lds, wave, seq, base, cnt, hp.k);
+        bool valid = lane < cnt;
+        uint64_t h1, h2;
+        kmer_hashes(lds, wave, lane, cnt, valid, hp, h1, h2);
+        ProbeIter it;
+        it.init(h1, h2, hp);
+        for (uint32_t i = 0; i < hp.num_hashes; ++i) {
+            uint32_t idx = it.get(i, hp);
+            if (valid) out[(base + lane) * hp.num_hashes + i] = idx;
+        }
+    }
+}
+void launch_debug_indices(const HashParams &hp, const uint8_t *d_seq, uint64_t len, uint64_t *d_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_debug_indices, dim3(64), dim3(256), 0, st, hp, d_seq, len, d_out);
+}
+
+__device__ __forceinline__ uint8_t acgt(uint32_t v) { return (uint8_t)((0x54474341u >> (8u * (v & 3u))) & 0xffu); }  // "ACGT"
+
+__global__ void __launch_bounds__(256) k_synth_genomes(uint8_t *out, uint64_t n_genomes, uint64_t len, uint64_t seed_base) {
+    const uint64_t words = (len + 31) / 32, total = n_genomes * words;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t g = t / words, w = t % words, v = rnd(seed_base + g, w);
+        for (uint32_t j = 0; j < 32 && w * 32 + j < len; ++j) out[g * len + w * 32 + j] = acgt((uint32_t)(v >> (2 * j)));
+    }
+}
+void launch_synth_genomes(uint8_t *d_out, uint64_t n_genomes, uint64_t genome_len, uint64_t seed_base, hipStream_t st) {
+    hipLaunchKernelGGL(k_synth_genomes, dim3(2048), dim3(256), 0, st, d_out, n_genomes, genome_len, seed_base);
+}
+
+__device__ __forceinline__ uint8_t comp_acgt(uint8_t b) { return b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : b == 'T' ? 'A' : b; }
+
+__global__ void __launch_bounds__(256) k_synth_reads(uint8_t *out, uint64_t first, uint64_t n_reads, uint64_t read_len,
+                                                     const uint8_t *genomes, uint64_t genome_len, uint64_t n_genomes, uint64_t seed) {
+    // one wave per read so the 150-byte rows are written coalesced
+    const uint32_t lane = lane_id();
+    const uint64_t wid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t c = wid; c < n_reads; c += nw) {
+        const uint64_t r = first + c, w0 = rnd(seed, 8 * r), w1 = rnd(seed, 8 * r + 1);
+        uint8_t *dst = out + c * read_len;
+        if ((w0 & 1ull) && n_genomes && genome_len >= read_len) {
+            const uint64_t g = (w0 >> 8) % n_genomes, o = w1 % (genome_len - read_len + 1);
+            const uint8_t *src = genomes + g * genome_len + o;
+            for (uint64_t j = lane; j < read_len; j += 64)
+                dst[j] = (w0 & 2ull) ? comp_acgt(src[read_len - 1 - j]) : src[j];
+        } else {
+            for (uint64_t j = lane; j < read_len; j += 64)
+                dst[j] = acgt((uint32_t)(rnd(seed ^ 0xA5A5A5A5A5A5A5A5ull, r * 64 + (j >> 5)) >> (2 * (j & 31))));
+        }
+    }
+}
+void launch_synth_reads(uint8_t *d_out, uint64_t first, uint64_t n_reads, uint64_t read_len, const uint8_t *d_genomes,
+                        uint64_t genome_len, uint64_t n_genomes, uint64_t seed, hipStream_t st) {
+    hipLaunchKernelGGL(k_synth_reads, dim3(4096), dim3(256), 0, st, d_out, first, n_reads, read_len, d_genomes, genome_len, n_genomes, seed);
+}
+
+}  // namespace pfq

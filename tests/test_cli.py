@@ -1,0 +1,186 @@
+"""The process-level drop-in seam: `phage_filter query` (main.rs:249-376) on the example-data fixture
+(tests/golden/examples, BASELINE config 1 plumbing case).  Expected outputs come from the CPU oracle; POS/NEG
+files are compared as multisets with genome lists as sets (record order and HashSet order are unspecified in
+the reference)."""
+import glob
+import gzip
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from oracle import pfq_format as fmt
+from oracle import pfq_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EX = os.path.join(ROOT, "tests", "golden", "examples")
+CLI = os.path.join(ROOT, "phagefilter_amd", "phage_filter")
+SEEDS = (0x0123456789ABCDEF, 0xFEDCBA9876543210)
+
+
+def fasta_records(path):
+    rid, seq = None, []
+    for line in open(path):
+        if line.startswith(">"):
+            if rid is not None:
+                yield rid, "".join(seq)
+            rid, seq = line[1:].split()[0], []
+        else:
+            seq.append(line.strip())
+    if rid is not None:
+        yield rid, "".join(seq)
+
+
+def fastq_records(path):
+    lines = open(path).read().split("\n")
+    for r in range(len(lines) // 4):
+        yield lines[4 * r][1:].split()[0], lines[4 * r + 1], lines[4 * r + 3]
+
+
+def example_tree():
+    ids, seqs = [], []
+    for f in sorted(glob.glob(os.path.join(EX, "genomes", "*.fna")))[::-1]:
+        for rid, seq in fasta_records(f):
+            ids.append(rid)
+            seqs.append(seq.encode())
+    nbits = orc.needed_bits(0.001, 1000000)
+    return orc.build_balanced_tree(seqs, ids, 20, nbits, orc.optimal_num_hashes(nbits, 1000000), SEEDS[0], SEEDS[1], 0.001, 1000000)
+
+
+def example_reads():
+    out = []
+    for f in sorted(glob.glob(os.path.join(EX, "reads", "*.fq")))[::-1]:
+        out += list(fastq_records(f))
+    return out
+
+
+def test_oracle_reproduces_examples_golden():
+    """CPU: the committed expected outputs are what the oracle computes today (regression pin)."""
+    gold = json.load(open(os.path.join(EX, "expected.json")))
+    t = example_tree()
+    assert [t.tax_id[v] for v in t.leaves_dfs()] == gold["genome_order"]
+    reads = example_reads()
+    assert len(reads) == gold["n_reads"]
+    hits, _, _ = orc.query_batch(t, [r[1].encode() for r in reads], 1.0, threads=4)
+    assert t.classification_csv() == gold["expected"]["1.0"]["classification_csv"]
+    assert len(hits) == gold["expected"]["1.0"]["n_hits"]
+
+
+def expected_filtering(t, reads, thr, block):
+    """POS/NEG records under the reference's per-block ResultMap semantics (main.rs:334-368, result_map.rs)."""
+    for v in range(t.n_nodes):
+        t.mapped_reads[v] = 0
+    hits, _, _ = orc.query_batch(t, [r[1].encode() for r in reads], thr, threads=4)
+    per_read = {}
+    for r, v in hits:
+        per_read.setdefault(r, set()).add(t.tax_id[v])
+    pos, neg = [], []
+    for b0 in range(0, len(reads), block):
+        rm = {}
+        for i in range(b0, min(len(reads), b0 + block)):
+            if i in per_read:
+                rm.setdefault(reads[i][0], set()).update(per_read[i])
+        for i in range(b0, min(len(reads), b0 + block)):
+            rid, seq, qual = reads[i]
+            if rid in rm:
+                pos.append((rid, frozenset(rm[rid]), seq.upper(), qual))
+            else:
+                neg.append((rid, frozenset(), seq.upper(), qual))
+    return sorted(pos, key=repr), sorted(neg, key=repr)
+
+
+def parse_filter_file(path, fastq):
+    recs = []
+    lines = open(path).read().split("\n")
+    step = 4 if fastq else 2
+    for r in range(len(lines) // step):
+        head = lines[step * r]
+        assert head[0] == ("@" if fastq else ">")
+        if " |" in head:
+            rid, genomes = head[1:].split(" |")
+            gs = frozenset(g for g in genomes.split(",") if g)
+        else:
+            rid, gs = head[1:], frozenset()
+        recs.append((rid, gs, lines[step * r + 1], lines[step * r + 3] if fastq else None))
+    return sorted(recs, key=repr)
+
+
+@pytest.fixture(scope="module")
+def cli_db(gpu, tmp_path_factory):
+    db = str(tmp_path_factory.mktemp("cli") / "db")
+    out = subprocess.run([CLI, "build-balanced", "--genomes", os.path.join(EX, "genomes"), "--db-path", db],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    return db
+
+
+@pytest.mark.gpu
+def test_cli_db_equals_oracle_tree(cli_db):
+    t = example_tree()
+    u = fmt.read_db(cli_db)
+    assert (u.kmer_size, u.nbits, u.num_hashes, u.seed1, u.seed2) == (20, t.nbits, 10, SEEDS[0], SEEDS[1])
+    assert u.tax_id == t.tax_id and u.left == t.left and u.right == t.right
+    for v in range(t.n_nodes):
+        assert (u.bits[u.filter_of[v]] == t.bits[v]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("thr,block", [("1.0", 100), ("0.7", 1000), ("0.3", 7)])
+def test_cli_query_examples(cli_db, tmp_path, thr, block):
+    gold = json.load(open(os.path.join(EX, "expected.json")))
+    outdir = str(tmp_path / "out")
+    os.makedirs(outdir)
+    open(os.path.join(outdir, "stale.txt"), "w").write("must be deleted")  # main.rs:380-391 wipes the directory
+    p = subprocess.run([CLI, "query", "--reads", os.path.join(EX, "reads"), "--out", outdir, "--db-path", cli_db,
+                        "--filter-threshold", thr, "--cache-size", "1", "--block-size-reads", str(block), "--threads", "4",
+                        "--pos-filter", "--neg-filter"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "Querying reads..." in p.stdout and p.stdout.strip().endswith("Finished.")
+    assert sorted(os.listdir(outdir)) == ["CLASSIFICATION.csv", "NEG_FILTERING.fq", "POS_FILTERING.fq"]
+    assert open(os.path.join(outdir, "CLASSIFICATION.csv")).read() == gold["expected"][thr]["classification_csv"]
+    pos, neg = expected_filtering(example_tree(), example_reads(), float(thr), block)
+    assert parse_filter_file(os.path.join(outdir, "POS_FILTERING.fq"), True) == pos
+    assert parse_filter_file(os.path.join(outdir, "NEG_FILTERING.fq"), True) == [(a, b, c, d) for a, b, c, d in neg]
+
+
+@pytest.mark.gpu
+def test_cli_formats_gz_fasta_single_file_and_depth(cli_db, tmp_path):
+    reads = example_reads()[:300]
+    fa = tmp_path / "reads.fasta"
+    with open(fa, "w") as f:
+        for rid, seq, _ in reads:
+            f.write(f">{rid} some description\n{seq[:60]}\n{seq[60:]}\n")       # multi-line FASTA
+    gz = tmp_path / "reads.fq.gz"
+    with gzip.open(gz, "wt") as f:
+        for rid, seq, qual in reads:
+            f.write(f"@{rid}\n{seq}\n+\n{qual}\n")
+    t = example_tree()
+    hits, _, _ = orc.query_batch(t, [r[1].encode() for r in reads], 1.0)
+    want = t.classification_csv()
+    for src, ext in ((fa, "fa"), (gz, "fq")):
+        out = str(tmp_path / f"out_{ext}")
+        p = subprocess.run([CLI, "query", "-r", str(src), "-o", out, "-d", cli_db, "--pos-filter"], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert open(os.path.join(out, "CLASSIFICATION.csv")).read() == want
+        assert os.path.exists(os.path.join(out, f"POS_FILTERING.{ext}")) and not os.path.exists(os.path.join(out, f"NEG_FILTERING.{ext}"))
+    # --search-depth prunes the tree: leaves become Internal_Node_* (bloom_tree.rs:302-330)
+    t = example_tree()
+    t.prune(2)
+    orc.query_batch(t, [r[1].encode() for r in reads], 1.0)
+    out = str(tmp_path / "out_depth")
+    p = subprocess.run([CLI, "query", "-r", str(gz), "-o", out, "-d", cli_db, "--search-depth", "2", "-F", "fastq"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "If using a search depth, use a filtering flag" in p.stdout and "Search depth settings: 2" in p.stdout
+    assert open(os.path.join(out, "CLASSIFICATION.csv")).read() == t.classification_csv()
+    assert os.listdir(out) == ["CLASSIFICATION.csv"]
+
+
+@pytest.mark.gpu
+def test_cli_errors_exit_like_a_panic(cli_db, tmp_path):
+    p = subprocess.run([CLI, "query", "-r", os.path.join(EX, "reads"), "-o", str(tmp_path / "o"), "-d", str(tmp_path / "nodb")],
+                       capture_output=True, text=True)
+    assert p.returncode == 101 and "tree.bin" in p.stderr
+    p = subprocess.run([CLI, "query", "-r", os.path.join(EX, "reads"), "-d", cli_db], capture_output=True, text=True)
+    assert p.returncode == 101 and "--out" in p.stderr

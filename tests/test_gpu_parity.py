@@ -1,0 +1,307 @@
+"""GPU parity tests: the HIP path (through the C ABI of libpfq) against the CPU oracle, bit-exact.
+
+Everything here is integer / byte / index work, so the bar is equality: k-mer probe indices, filter words,
+per-leaf counts, per-read hit sets and CLASSIFICATION.csv bytes.  Run with `pytest -m gpu` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pfq_format as fmt
+from oracle import pfq_oracle as orc
+from phagefilter_amd import BloomTree, PfqError, ResultMap, pack_reads, query_batch
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(20240601)
+
+
+def rand_dna(n, alphabet=b"ACGT"):
+    return RNG.choice(np.frombuffer(alphabet, dtype=np.uint8), int(n)).astype(np.uint8).tobytes()
+
+
+def make_reads(genomes, n_pos, n_neg, length, k, *, errors=True):
+    reads = []
+    for i in range(n_pos):
+        g = genomes[int(RNG.integers(0, len(genomes)))]
+        L = int(min(length, len(g)))
+        o = int(RNG.integers(0, len(g) - L + 1))
+        r = bytearray(g[o:o + L])
+        if errors and i % 4 == 1 and L > 3:
+            r[int(RNG.integers(0, L))] = ord("N")
+        if errors and i % 7 == 2 and L > 3:
+            p = int(RNG.integers(0, L))
+            r[p] = ord("ACGT"[(b"ACGT".find(bytes([r[p]])) + 1) % 4]) if bytes([r[p]]) in b"ACGT" else r[p]
+        if i % 3 == 0:
+            r = bytearray(orc.revcomp(bytes(r)))
+        if errors and i % 11 == 5:
+            r = bytearray(bytes(r).lower())
+        reads.append(bytes(r))
+    reads += [rand_dna(length) for _ in range(n_neg)]
+    reads += [b"", b"A", rand_dna(max(k - 1, 0)), rand_dna(k), rand_dna(k + 1)]
+    order = RNG.permutation(len(reads))
+    return [reads[i] for i in order]
+
+
+def oracle_tree(genomes, k, nbits, h, seeds=(5, 10)):
+    ids = [f"G{i:05d}" for i in range(len(genomes))]
+    return orc.build_balanced_tree(genomes, ids, k, nbits, h, seeds[0], seeds[1]), ids
+
+
+def gpu_tree(genomes, ids, k, nbits, h, seeds=(5, 10)):
+    return BloomTree.build_balanced(genomes, ids, k, nbits, h, seeds[0], seeds[1])
+
+
+def hits_of(offs, leaves):
+    return sorted((r, int(leaves[j])) for r in range(len(offs) - 1) for j in range(int(offs[r]), int(offs[r + 1])))
+
+
+def oracle_hits(t, hits):
+    col = {v: i for i, v in enumerate(t.leaves_dfs())}
+    return sorted((r, col[v]) for r, v in hits)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K1: canonical k-mer + FxHash + double hashing + exact mod
+# ---------------------------------------------------------------------------------------------------------------
+K1_CASES = [(k, nbits, h, s) for k in (1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 20, 21, 31, 32, 33, 47, 48, 49, 63, 64)
+            for nbits, h, s in ((14378, 10, (5, 10)),)] + [
+    (21, 71887936, 10, (0x0123456789ABCDEF, 0xFEDCBA9876543210)),
+    (20, 11981322, 17, (0xFFFFFFFFFFFFFFFF, 1)),
+    (21, 1 << 20, 10, (7, 9)),
+    (21, (1 << 32) - 1, 12, (3, 4)),
+    (21, 1, 3, (3, 4)),
+    (21, 3, 200, (0, 0)),
+    (31, 4294967291, 5, (11, 13)),
+]
+
+
+@pytest.mark.parametrize("k,nbits,h,seeds", K1_CASES)
+def test_kmer_indices_match_oracle(gpu, k, nbits, h, seeds):
+    t = gpu_tree([rand_dna(max(k, 4))], ["g"], k, nbits, h, seeds)
+    seqs = [rand_dna(300), rand_dna(200, b"ACGTN"), rand_dna(150, b"acgtACGTNnRYKMSWBDHVryx-*"),
+            b"ACGT" * 40, b"A" * 130, (b"ACGTACGTAC" + b"GTACGTACGT") * 8, rand_dna(k), rand_dna(k + 63), rand_dna(k + 64),
+            bytes(RNG.integers(0, 256, 257, dtype=np.uint8))]
+    for s in seqs:
+        got = t.kmer_indices(s)
+        kmers = orc.get_kmers(s, k)
+        assert got.shape == (len(kmers), h)
+        want = np.array([orc.probe_indices(seeds[0], seeds[1], h, nbits, km) for km in kmers], dtype=np.uint64).reshape(len(kmers), h)
+        assert np.array_equal(got, want), (k, nbits, s[:40])
+    assert t.kmer_indices(rand_dna(max(k - 1, 0))).shape[0] == 0
+    t.close()
+
+
+def test_unsupported_parameters_fail_loudly(gpu):
+    with pytest.raises(PfqError):
+        gpu_tree([rand_dna(100)], ["g"], 65, 1000, 3)
+    with pytest.raises(PfqError):
+        gpu_tree([rand_dna(100)], ["g"], 0, 1000, 3)
+    with pytest.raises(PfqError):
+        gpu_tree([rand_dna(100)], ["g"], 21, 1 << 32, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# database construction: filters of every node equal the oracle's
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_genomes,k,nbits,h", [(1, 21, 50021, 7), (2, 5, 14378, 10), (5, 20, 100003, 10), (8, 31, 65536, 4),
+                                                  (13, 21, 200000, 10)])
+def test_balanced_build_matches_oracle(gpu, n_genomes, k, nbits, h):
+    genomes = [rand_dna(int(RNG.integers(k, 3000)), b"ACGTN" if i % 3 == 0 else b"ACGT") for i in range(n_genomes)]
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    gt = gpu_tree(genomes, ids, k, nbits, h)
+    info = gt.info()
+    assert (info.n_nodes, info.n_leaves, info.superset_verified) == (ot.n_nodes, n_genomes, 1)
+    for v in range(ot.n_nodes):
+        assert np.array_equal(gt.node_filter(v), ot.bits[ot.filter_of[v]]), v
+    assert [t for t, _ in gt.get_leaf_counts()] == [t for t, _ in ot.leaf_counts()]
+    gt.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# query parity
+# ---------------------------------------------------------------------------------------------------------------
+def check_query(gt, ot, reads, thr, path=-1):
+    gt.reset_counts()
+    for v in range(ot.n_nodes):
+        ot.mapped_reads[v] = 0
+    gt.set_path(path)
+    seq, off = pack_reads(reads)
+    offs, leaves = gt.query_packed(seq, off, thr, want_hits=True)
+    ohits, _, _ = orc.query_batch(ot, reads, thr)
+    assert gt.get_leaf_counts() == ot.leaf_counts(), (thr, path)
+    assert hits_of(offs, leaves) == oracle_hits(ot, ohits), (thr, path)
+    st = gt.last_stats()
+    assert st.n_hits + st.n_allhit_reads * len(ot.leaves_dfs()) == len(ohits)
+    return st
+
+
+TREES = [(1, 21, 30011, 5), (2, 21, 30011, 10), (3, 11, 20000, 3), (8, 21, 100003, 10), (33, 20, 150001, 10), (64, 21, 65536, 6),
+         (70, 16, 200003, 10), (130, 21, 262144, 10)]
+
+
+@pytest.mark.parametrize("n_genomes,k,nbits,h", TREES)
+def test_query_matches_oracle(gpu, n_genomes, k, nbits, h):
+    genomes = [rand_dna(int(RNG.integers(300, 1500))) for _ in range(n_genomes)]
+    if n_genomes > 3:
+        genomes[1] = genomes[0][:200] + genomes[1][200:]          # shared prefix: reads hit several leaves
+        genomes[2] = genomes[0]                                    # identical twin
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    gt = gpu_tree(genomes, ids, k, nbits, h)
+    reads = make_reads(genomes, 150, 60, 150, k) + make_reads(genomes, 10, 5, 700, k) + make_reads(genomes, 20, 5, k + 2, k)
+    for thr in (1.0, 0.0, 0.3, 0.5, 0.75, 0.999, 1.5, -1.0, float("nan")):
+        st = check_query(gt, ot, reads, thr, path=0)
+        assert st.path == 0
+    st = check_query(gt, ot, reads, 1.0, path=1)                   # bucketed: screen + L2-sliced verify
+    assert st.path == 1
+    gt.close()
+
+
+def test_counts_accumulate_and_want_hits_off(gpu):  # query.rs:143, :356-380
+    genomes = [rand_dna(800) for _ in range(6)]
+    ot, ids = oracle_tree(genomes, 21, 60000, 8)
+    gt = gpu_tree(genomes, ids, 21, 60000, 8)
+    a, b = make_reads(genomes, 80, 30, 100, 21), make_reads(genomes, 50, 50, 150, 21)
+    for reads, thr in ((a, 1.0), (b, 0.4), (a, 0.0)):
+        seq, off = pack_reads(reads)
+        assert gt.query_packed(seq, off, thr, want_hits=False) is None
+        orc.query_batch(ot, reads, thr)
+    assert gt.get_leaf_counts() == ot.leaf_counts()
+    gt.close()
+
+
+def test_reference_query_fixtures_on_gpu(gpu):  # query.rs:267-380 through the reference-shaped host interface
+    nbits = orc.needed_bits(0.001, 1000)
+    h = orc.optimal_num_hashes(nbits, 1000)
+    t = BloomTree.build_balanced([b"ATCGCA"], ["genome"], 3, nbits, h, 5, 10)
+    for reads, thr, want in (([b"ATCG"], 1.0, 1), ([b"AAAA"], 1.0, 0), ([b"ATCG", b"AAAA"], 0.0, 2)):
+        t.reset_counts()
+        query_batch(t, reads, thr)
+        assert t.get_leaf_counts() == [("genome", want)]
+    t.close()
+    four = [b"ATCAG", b"TTTAG", b"CTCAG", b"ATTAG"]
+    names = ["baseline", "diff", "onediff_first", "onediff_mid"]
+    t = BloomTree.build_balanced(four, names, 4, nbits, h, 5, 10)
+    rm = ResultMap()
+    query_batch(t, [b"TCAG"], 0.1, rm, ["read_tcag"])
+    query_batch(t, [b"ATCA"], 0.1, rm, ["read_atca"])
+    c = dict(t.get_leaf_counts())
+    assert c["baseline"] >= 2 and c["diff"] == 0
+    assert rm.read_mapped("read_tcag") and "baseline" in rm.get_ext_id("read_tcag")
+    t.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# database files: reader, writer, CLASSIFICATION.csv, irregular trees
+# ---------------------------------------------------------------------------------------------------------------
+def test_db_load_save_and_csv(gpu, tmp_path):
+    genomes = [rand_dna(int(RNG.integers(400, 900))) for _ in range(9)]
+    ot, ids = oracle_tree(genomes, 20, 80021, 10, seeds=(0xDEADBEEF12345678, 0x0BADF00D87654321))
+    d1 = str(tmp_path / "db1")
+    fmt.write_db(ot, d1)
+    gt = BloomTree.load(d1)
+    i = gt.info()
+    assert (i.kmer_size, i.nbits, i.num_hashes, i.seed1, i.seed2, i.n_nodes, i.superset_verified) == (
+        20, 80021, 10, 0xDEADBEEF12345678, 0x0BADF00D87654321, ot.n_nodes, 1)
+    reads = make_reads(genomes, 120, 40, 120, 20)
+    check_query(gt, ot, reads, 1.0)
+    check_query(gt, ot, reads, 0.35)
+    out = str(tmp_path / "CLASSIFICATION.csv")
+    gt.save_leaf_counts(out)
+    assert open(out).read() == ot.classification_csv()
+    # writer: what the product saves, the format restatement reads back identically
+    d2 = str(tmp_path / "db2")
+    gt.save(d2)
+    u = fmt.read_db(d2)
+    assert (u.kmer_size, u.nbits, u.num_hashes, u.seed1, u.seed2) == (20, 80021, 10, ot.seed1, ot.seed2)
+    assert u.left == ot.left and u.right == ot.right and u.tax_id == ot.tax_id and u.bf_path == ot.bf_path
+    assert u.mapped_reads == ot.mapped_reads
+    for v in range(ot.n_nodes):
+        assert np.array_equal(u.bits[u.filter_of[v]], ot.bits[ot.filter_of[v]])
+    gt.close()
+    with pytest.raises(PfqError):
+        BloomTree.load(str(tmp_path / "missing"))
+    os.remove(os.path.join(d1, ot.bf_path[3]))
+    with pytest.raises(PfqError):
+        BloomTree.load(d1)
+
+
+def test_non_superset_and_shared_filters(gpu, tmp_path):
+    """Trees the reference can produce: an internal filter that lost bits, and two nodes naming one
+    .bf.  The walk is then not pure pruning; results must still equal the full reference traversal."""
+    genomes = [rand_dna(600) for _ in range(8)]
+    ot, ids = oracle_tree(genomes, 21, 50021, 6)
+    internal = [v for v in range(ot.n_nodes) if not ot.is_leaf(v)]
+    ot.bits[ot.filter_of[internal[1]]][::2] = 0                 # drop half the words of one internal filter
+    ot.bits[ot.filter_of[internal[-1]]][:] = 0                  # and blank another
+    a, b = internal[2], internal[3]
+    ot.bf_path[b] = ot.bf_path[a]                               # name collision: two nodes alias one filter
+    ot.filter_of[b] = ot.filter_of[a]
+    d = str(tmp_path / "db")
+    fmt.write_db(ot, d)
+    gt = BloomTree.load(d)
+    assert gt.info().superset_verified == 0
+    reads = make_reads(genomes, 200, 40, 150, 21, errors=False)
+    for thr in (1.0, 0.6, 0.0):
+        check_query(gt, ot, reads, thr)
+    gt.close()
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2, 3, 10])
+def test_prune_tree_matches_oracle(gpu, depth):  # bloom_tree.rs:302-330
+    genomes = [rand_dna(500) for _ in range(11)]
+    ot, ids = oracle_tree(genomes, 21, 40009, 5)
+    gt = gpu_tree(genomes, ids, 21, 40009, 5)
+    ot.prune(depth)
+    gt.prune_tree(depth)
+    assert [t for t, _ in gt.get_leaf_counts()] == [t for t, _ in ot.leaf_counts()]
+    reads = make_reads(genomes, 100, 30, 150, 21)
+    check_query(gt, ot, reads, 1.0)
+    check_query(gt, ot, reads, 0.5)
+    gt.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# synthetic workload generators (bench data) and a BASELINE config-2-shaped case
+# ---------------------------------------------------------------------------------------------------------------
+def test_synthetic_generators_match_oracle(gpu):
+    import torch
+    from phagefilter_amd import _ffi
+    n_g, glen, rlen, n_r = 5, 1000, 150, 4000
+    dg = torch.empty(n_g * glen, dtype=torch.uint8, device="cuda")
+    _ffi.check(_ffi.lib().pfq_synth_genomes_device(dg.data_ptr(), n_g, glen, 0x5EED0000, None))
+    want_g = np.stack([np.frombuffer(orc.synth_genome(0x5EED0000 + i, glen), dtype=np.uint8) for i in range(n_g)])
+    torch.cuda.synchronize()
+    assert np.array_equal(dg.cpu().numpy().reshape(n_g, glen), want_g)
+    dr = torch.empty(n_r * rlen, dtype=torch.uint8, device="cuda")
+    _ffi.check(_ffi.lib().pfq_synth_reads_device(dr.data_ptr(), 100, n_r, rlen, dg.data_ptr(), glen, n_g, 0x5EED1234, None))
+    torch.cuda.synchronize()
+    want_r = orc.synth_reads(0x5EED1234, 100, n_r, rlen, want_g, glen)
+    assert np.array_equal(dr.cpu().numpy().reshape(n_r, rlen), want_r)
+
+
+def test_config2_shape_64_leaves_k21(gpu):
+    """BASELINE config 2 shape (64-leaf SBT, k=21, 150 bp, theta=1, 50/50 mix) at a size the oracle finishes in
+    seconds: nbits scaled down with the genome length so the fill profile matches (0.69 % per leaf)."""
+    n_g, glen, k, h = 64, 5000, 21, 10
+    nbits = 7188793
+    genomes_np = np.stack([np.frombuffer(orc.synth_genome(0x5EED0000 + i, glen), dtype=np.uint8) for i in range(n_g)])
+    genomes = [g.tobytes() for g in genomes_np]
+    ot, ids = oracle_tree(genomes, k, nbits, h, seeds=(0x0123456789ABCDEF, 0xFEDCBA9876543210))
+    gt = gpu_tree(genomes, ids, k, nbits, h, seeds=(0x0123456789ABCDEF, 0xFEDCBA9876543210))
+    n_reads = 300000
+    reads_np = orc.synth_reads(0x5EED1234, 0, n_reads, 150, genomes_np, glen)
+    seq = np.concatenate([reads_np.reshape(-1), np.zeros(16, dtype=np.uint8)])
+    off = (np.arange(n_reads + 1, dtype=np.uint64) * 150)
+    ohits, _, _ = orc.query_batch_packed(ot, seq, off, 1.0, threads=8)
+    for path in (0, 1):
+        gt.reset_counts()
+        gt.set_path(path)
+        offs, leaves = gt.query_packed(seq, off, 1.0, want_hits=True)
+        assert gt.get_leaf_counts() == ot.leaf_counts()
+        got = np.stack([np.repeat(np.arange(n_reads), np.diff(offs).astype(np.int64)), leaves.astype(np.int64)], 1)
+        want = np.array(oracle_hits(ot, ohits), dtype=np.int64).reshape(-1, 2)
+        assert np.array_equal(got, want)
+        assert gt.last_stats().path == path
+    # every positive read hits (at least) its source leaf: about half of the reads
+    assert 0.49 * n_reads < len(ohits) < 0.52 * n_reads
+    gt.close()
