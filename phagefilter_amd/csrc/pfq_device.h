@@ -43,20 +43,24 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
 __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
-// bio::alphabets::dna complement (bio 2.2.0; used by file_parser.rs:115): identity except the IUPAC pairs and
-// their lowercase forms.  Filled once per block.
-__device__ __forceinline__ void fill_complement(uint8_t *comp) {
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-        uint32_t u = i & ~32u, o = 0;  // u in 'A'..'Z' only if i is a letter (either case)
-        switch (u) {
-            case 'A': o = 'T'; break; case 'T': o = 'A'; break; case 'G': o = 'C'; break; case 'C': o = 'G'; break;
-            case 'Y': o = 'R'; break; case 'R': o = 'Y'; break; case 'W': o = 'W'; break; case 'S': o = 'S'; break;
-            case 'K': o = 'M'; break; case 'M': o = 'K'; break; case 'D': o = 'H'; break; case 'H': o = 'D'; break;
-            case 'V': o = 'B'; break; case 'B': o = 'V'; break; case 'N': o = 'N'; break;
-            default: break;
+// bio::alphabets::dna complement (bio 2.2.0; used by file_parser.rs:115): identity except the IUPAC pairs
+// A<->T C<->G Y<->R W<->W S<->S K<->M D<->H V<->B N<->N and their lowercase forms.  Built at compile time,
+// copied to LDS once per block.
+struct CompTable {
+    uint8_t t[256];
+    constexpr CompTable() : t{} {
+        for (int i = 0; i < 256; ++i) t[i] = (uint8_t)i;
+        const char a[] = "AGCTYRWSKMDVHBN", b[] = "TCGARYWSMKHBDVN";
+        for (int i = 0; i < 15; ++i) {
+            t[(uint8_t)a[i]] = (uint8_t)b[i];
+            t[(uint8_t)a[i] + 32] = (uint8_t)(b[i] + 32);
         }
-        comp[i] = (uint8_t)(o ? (o | (i & 32u)) : i);  // mapped letters keep the input's case
     }
+};
+__device__ __constant__ const CompTable COMP_TABLE{};
+__device__ __forceinline__ void fill_complement(uint8_t *comp) {
+    for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x)
+        reinterpret_cast<uint32_t *>(comp)[i] = reinterpret_cast<const uint32_t *>(COMP_TABLE.t)[i];
 }
 
 // ---- LDS byte-granular reads ----------------------------------------------------------------------------------
@@ -186,10 +190,18 @@ struct ProbeIter {
         uint64_t rn = r + h2;
         bool carry = rn < r;
         r = rn;
-        uint64_t t = (uint64_t)x + g + (carry ? (hp.nbits - hp.w64) : 0ull);  // < 3d
-        t -= (t >= hp.nbits) ? hp.nbits : 0;
-        t -= (t >= hp.nbits) ? hp.nbits : 0;
-        x = (uint32_t)t;
+        if (hp.nbits < (1ull << 30)) {  // wave-uniform: 32-bit residue arithmetic, x + g + (d - w) < 3d < 2^32
+            const uint32_t d = (uint32_t)hp.nbits;
+            uint32_t t = x + g + (carry ? d - (uint32_t)hp.w64 : 0u);
+            t = min(t, t - d);  // t >= d ? t - d : t   (t - d wraps to a huge value when t < d)
+            t = min(t, t - d);
+            x = t;
+        } else {
+            uint64_t t = (uint64_t)x + g + (carry ? (hp.nbits - hp.w64) : 0ull);  // < 3d
+            t -= (t >= hp.nbits) ? hp.nbits : 0;
+            t -= (t >= hp.nbits) ? hp.nbits : 0;
+            x = (uint32_t)t;
+        }
         return x;
     }
 };

@@ -381,12 +381,12 @@ int ensure_scratch(pfq_tree &t, uint64_t n_reads, bool want_hits) {
     return PFQ_OK;
 }
 int ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads) {
-    const uint64_t cap = 2 * n_reads + 1024;
+    const uint64_t cap = 2 * n_reads + 32 * 8192 + 1024;  // + one partially used reservation per wave
     HIP_TRY(t.d_pairs.ensure(cap));
     HIP_TRY(t.d_sorted.ensure(cap));
     HIP_TRY(t.d_fail.ensure(cap));
     HIP_TRY(t.d_bucket.ensure(3 * t.leaves.size() + 2));
-    HIP_TRY(t.d_queue.ensure(16));
+    HIP_TRY(t.d_queue.ensure(16));  // (unused by the lock-step verify; kept zeroed)
     return PFQ_OK;
 }
 
@@ -451,11 +451,13 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             if (bucketed) {
                 uint32_t *cnt = t.d_bucket.p, *off = cnt + nl, *cur = off + nl + 1;
                 a.pairs = t.d_pairs.p;
-                a.pair_cap = t.d_pairs.n;
+                a.pair_cap = t.d_pairs.n & ~31ull;  // whole reservations only (PAIR_CHUNK = 32)
                 a.pair_cursor = t.d_cursors.p + 1;
                 a.bucket_cnt = cnt;
                 uint32_t n_slices = 1;
-                while (n_slices < 8 && (t.n_words * 8 + n_slices - 1) / n_slices > SLICE_TARGET_BYTES) n_slices <<= 1;
+                uint64_t slice_target = SLICE_TARGET_BYTES;
+                if (const char *e = getenv("PFQ_SLICE_KB")) slice_target = strtoull(e, nullptr, 10) << 10;
+                while (n_slices < 8 && (t.n_words * 8 + n_slices - 1) / n_slices > slice_target) n_slices <<= 1;
                 t.last_slices = n_slices;
                 HIP_TRY(hipMemsetAsync(cnt, 0, nl * 4, st));
                 HIP_TRY(hipMemsetAsync(t.d_fail.p, 0, t.d_fail.n * 4, st));
@@ -463,7 +465,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 pfq::launch_classify(a, true, false, blocks, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
                 pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nl, st);
-                pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, t.d_pairs.n, off, cur, t.d_sorted.p, 1024, st);
+                pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, t.d_sorted.p, 1024, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[2], st));
                 pfq::VerifyArgs v{};
                 v.hp = t.hp;
@@ -473,15 +475,19 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 v.col_row = t.d_col_row.p;
                 v.n_words = t.n_words;
                 v.sorted = t.d_sorted.p;
-                v.n_pairs_ptr = t.d_cursors.p + 1;
-                v.pair_cap = t.d_pairs.n;
+                v.n_pairs_ptr = off + nl;
                 v.fail = t.d_fail.p;
                 v.n_slices = n_slices;
                 uint64_t sb = (t.n_words * 64 + n_slices - 1) / n_slices;
                 v.slice_bits = (uint32_t)((sb + 63) & ~63ull);
                 v.queue = t.d_queue.p;
-                v.chunk = 16;
-                pfq::launch_verify(v, 2048, st);
+                // window of pairs in flight per slice = (blocks/8)*(8/n_slices)*4*chunk: about one leaf bucket
+                int vblocks = 1024;
+                v.chunk = 4;
+                if (const char *e = getenv("PFQ_VERIFY_BLOCKS")) vblocks = std::max(8, atoi(e) & ~7);
+                if (const char *e = getenv("PFQ_VERIFY_DEBUG")) v.debug = (uint32_t)atoi(e);
+                if (const char *e = getenv("PFQ_VERIFY_CHUNK")) v.chunk = (uint32_t)std::max(1, atoi(e));
+                pfq::launch_verify(v, vblocks, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[3], st));
                 pfq::FinalizeArgs f{};
                 f.hp = t.hp;

@@ -50,12 +50,12 @@ struct VerifyArgs {
     const uint32_t *col_row;     // column -> filter row
     uint64_t n_words;
     const uint2 *sorted;         // (read, leaf) sorted by leaf
-    const unsigned long long *n_pairs_ptr;
-    uint64_t pair_cap;
+    const uint32_t *n_pairs_ptr; // &bucket_off[n_leaves]
     uint32_t *fail;              // [pair_cap]
     uint32_t n_slices, slice_bits;
     unsigned int *queue;         // [n_slices] work cursors
     uint32_t chunk;
+    uint32_t debug;              // measurement switches (PFQ_VERIFY_DEBUG): 1 = probe leaf 0 only, 2 = no probe loads
 };
 
 struct FinalizeArgs {

@@ -18,6 +18,7 @@ namespace pfq {
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((31u << 11) | 20u) & 0xFu; }
 
 constexpr uint32_t SCREEN_ROUNDS = 2;  // row loads in flight per lane and probe in the theta=1 screen
+constexpr uint32_t PAIR_CHUNK = 32;    // slots a wave reserves at a time in the deferred-pair buffer
 constexpr uint32_t NPLANES = 16;       // vertical-counter planes of the theta<1 screen (k-mers per read < 65536)
 
 struct ReadCtx {
@@ -161,6 +162,10 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
     uint32_t colmask = 0;  // leaf columns of my dword
     if (word * 32u < a.n_leaves) colmask = (a.n_leaves - word * 32u >= 32u) ? ~0u : ((1u << (a.n_leaves - word * 32u)) - 1u);
     unsigned long long st_cand = 0, st_hits = 0, st_all = 0, st_bytes = 0, st_def = 0;
+    // deferred pairs are appended through per-wave reservations of PAIR_CHUNK slots: one atomic on the shared
+    // cursor per chunk (a single hot address saturates at ~88 atomics/us); unused slots are voided at the end
+    unsigned long long pair_base = 0;
+    uint32_t pair_used = PAIR_CHUNK;
 
     for (uint64_t r = gw; r < a.n_reads; r += nw) {
         const uint64_t o0 = a.off[r], L = a.off[r + 1] - o0;
@@ -192,17 +197,25 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             if ((int)lane == src) live &= ~(1u << bit);
             ++st_cand;
             if (DEFER) {
-                uint32_t pushed = 0;
-                if (lane == 0) {
-                    unsigned long long pos = atomicAdd(a.pair_cursor, 1ull);
-                    if (pos < a.pair_cap) {
-                        a.pairs[pos] = make_uint2((uint32_t)r, col);
-                        atomicAdd(&a.bucket_cnt[col], 1u);
-                        pushed = 1;
+                if (pair_used == PAIR_CHUNK) {  // wave-uniform
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(a.pair_cursor, (unsigned long long)PAIR_CHUNK);
+                    base = ((unsigned long long)bcast_u32((uint32_t)(base >> 32), 0) << 32) | bcast_u32((uint32_t)base, 0);
+                    if (base + PAIR_CHUNK <= a.pair_cap) {
+                        pair_base = base;
+                        pair_used = 0;
                     }
                 }
-                pushed = bcast_u32(pushed, 0);
-                if (pushed) { ++st_def; continue; }
+                if (pair_used < PAIR_CHUNK) {
+                    if (lane == 0) {
+                        a.pairs[pair_base + pair_used] = make_uint2((uint32_t)r, col);
+                        atomicAdd(&a.bucket_cnt[col], 1u);
+                    }
+                    ++pair_used;
+                    ++st_def;
+                    continue;
+                }
+                // no room left in the pair buffer: certify inline below (results stay exact)
             }
             bool pass = verify_column(lds, wave, a, rc, col);
             // ancestors that are not provably supersets must pass too (query.rs:119-141 visits children only with
@@ -222,6 +235,8 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             }
         }
     }
+    if (DEFER && pair_used < PAIR_CHUNK)
+        for (uint32_t i = pair_used + lane; i < PAIR_CHUNK; i += 64) a.pairs[pair_base + i] = make_uint2(0xffffffffu, 0xffffffffu);
     // reads that pass every node (need == 0) count at every leaf (query.rs:143 reached through every path)
     if (st_all)
         for (uint32_t c = lane; c < a.n_leaves; c += 64) atomicAdd(&a.counts[c], st_all);
@@ -275,6 +290,7 @@ __global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, cons
     if (n > pair_cap) n = pair_cap;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint2 p = pairs[i];
+        if (p.y == 0xffffffffu) continue;  // voided slot of a partially used reservation
         uint32_t pos = atomicAdd(&cur[p.y], 1u);
         sorted[off[p.y] + pos] = p;
     }
@@ -285,34 +301,39 @@ void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs
 }
 
 // ---- K2 for bucketed survivors: L2-resident filter slices ------------------------------------------------------------
-// Work item = `chunk` consecutive sorted pairs x one slice of the filter's bit range.  A wave prefers the slice
-// its XCD is responsible for (XCC_ID % n_slices), so the 32 CUs of an XCD keep gathering from the same <= 2.5 MB
-// of the current leaf's filter, which therefore stays in that XCD's 4 MiB L2 (speed only; any wave may take any
-// item).  theta == 1 only: every probed bit must be set, so slices are independent and any miss fails the pair.
+// The pairs are sorted by leaf.  Every block serves one slice of the filters' bit range at a time and pulls
+// items (4*chunk consecutive sorted pairs) from that slice's queue, so all blocks of a slice stay within a window
+// of (blocks per slice)*item pairs = about one leaf bucket (a static split drifts apart and thrashes the L2).
+// Blocks are dealt to XCDs round-robin, so with home slice = XCC_ID % n_slices all CUs of an XCD gather from
+// the same <= 2.5 MB slice of the current leaf, which therefore stays in that XCD's 4 MiB L2.  Placement only
+// affects speed: every (item, slice) is taken exactly once whatever the placement, and a block whose home queue
+// is drained helps with the other slices.  theta == 1 only: every probed bit must be set, so slices are
+// independent and any miss fails the pair.
 __global__ void __launch_bounds__(256) k_verify(VerifyArgs a) {
     __shared__ BlockLds lds;
+    __shared__ uint32_t s_item;
     fill_complement(lds.comp);
-    __syncthreads();
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    uint64_t n_pairs = *a.n_pairs_ptr;
-    if (n_pairs > a.pair_cap) n_pairs = a.pair_cap;
-    const uint64_t n_items = (n_pairs + a.chunk - 1) / a.chunk;
+    const uint64_t n_pairs = *a.n_pairs_ptr;  // = bucket_off[n_leaves]: deferred pairs, voided slots excluded
+    const uint32_t per_wave = a.chunk, item_pairs = per_wave * WAVES_PER_BLOCK;
+    const uint64_t n_items = (n_pairs + item_pairs - 1) / item_pairs;
     const uint32_t home = xcc_id() % a.n_slices;
     for (uint32_t att = 0; att < a.n_slices; ++att) {
         const uint32_t s = (home + att) % a.n_slices;
         const uint32_t lo = s * a.slice_bits;
         while (true) {
-            uint32_t item = 0;
-            if (lane == 0) item = atomicAdd(&a.queue[s], 1u);
-            item = bcast_u32(item, 0);
-            if (item >= n_items) break;
-            uint64_t e0 = (uint64_t)item * a.chunk, e1 = e0 + a.chunk < n_pairs ? e0 + a.chunk : n_pairs;
+            __syncthreads();  // everyone is done with the previous item (and, first time, the complement table is filled)
+            if (threadIdx.x == 0) s_item = atomicAdd(&a.queue[s], 1u);
+            __syncthreads();
+            const uint64_t it = s_item;
+            if (it >= n_items) break;
+            uint64_t e0 = it * item_pairs + (uint64_t)wave * per_wave, e1 = e0 + per_wave < n_pairs ? e0 + per_wave : n_pairs;
             for (uint64_t e = e0; e < e1; ++e) {
                 const uint2 p = a.sorted[e];
                 const uint64_t o0 = a.off[p.x], L = a.off[p.x + 1] - o0;
                 const uint64_t n = L - a.hp.k + 1;  // candidates always have n >= 1
                 const uint8_t *read = a.seq + o0;
-                const uint32_t *bm = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)a.col_row[p.y] * a.n_words);
+                const uint32_t *bm = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)a.col_row[(a.debug & 1u) ? 0u : p.y] * a.n_words);
                 bool miss = false;
                 for (uint64_t base = 0; base < n; base += WIN_KMERS) {
                     uint32_t cnt = (uint32_t)((n - base) < WIN_KMERS ? (n - base) : WIN_KMERS);
@@ -320,15 +341,15 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs a) {
                     bool valid = lane < cnt;
                     uint64_t h1, h2;
                     kmer_hashes(lds, wave, lane, cnt, valid, a.hp, h1, h2);
-                    ProbeIter it;
-                    it.init(h1, h2, a.hp);
+                    ProbeIter pit;
+                    pit.init(h1, h2, a.hp);
                     uint32_t ok = 1;
 #pragma unroll 5
                     for (uint32_t i = 0; i < a.hp.num_hashes; ++i) {
-                        uint32_t idx = it.get(i, a.hp);
-                        bool in = valid && (idx - lo) < a.slice_bits;
+                        uint32_t idx = pit.get(i, a.hp);
+                        bool in = valid && (idx - lo) < a.slice_bits && !(a.debug & 2u);
                         uint32_t v = in ? bm[idx >> 5] : ~0u;
-                        ok &= (v >> (idx & 31u));
+                        ok &= (v >> (idx & 31u)) | (a.debug & 1u) | (idx & a.debug & 4u);
                     }
                     miss = !(ok & 1u);
                     if (ballot64(miss)) { miss = true; break; }
