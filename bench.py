@@ -57,6 +57,7 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     from phagefilter_amd import BloomTree, _ffi
+    from phagefilter_amd.dist import all_reduce_counts
     L = _ffi.lib()
     n_g, glen, rl, B = args.leaves, args.genome_len, args.read_len, args.reads_per_step
     ids = [f"G{i:05d}" for i in range(n_g)]
@@ -106,8 +107,7 @@ def main() -> None:
     for i in range(args.steps):
         step(args.warmup + i)
     tree.export_counts(counts.data_ptr(), stream)
-    if world > 1:
-        dist.all_reduce(counts)  # RCCL over xGMI: 8 KiB at 1024 leaves
+    all_reduce_counts(counts)  # one RCCL all-reduce over xGMI (8 KiB at 1024 leaves); no-op at N = 1
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -159,6 +159,18 @@ def main() -> None:
             "hits_total": total_hits, "hits_last_step": int(st.n_hits), "candidates_last_step": int(st.n_candidates),
             "setup_seconds": setup_s,
         }
+
+    # ---- PCIe-inclusive rate: the same block handed over as HOST buffers (pfq_query_batch); never `value`
+    if rank == 0 and world == 1:
+        h_seq = np.concatenate([reads[:B * rl].cpu().numpy(), np.zeros(16, dtype=np.uint8)])
+        h_off = np.arange(B + 1, dtype=np.uint64) * rl
+        best = None
+        for _ in range(2):
+            t_h = time.perf_counter()
+            tree.query_packed(h_seq, h_off, args.threshold)
+            dt = time.perf_counter() - t_h
+            best = dt if best is None else min(best, dt)
+        result["host_buffers_reads_per_s"] = B / best
 
     # ---- CPU baseline: oracle in reference-faithful mode on the host cores (rank 0, N = 1 only)
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
