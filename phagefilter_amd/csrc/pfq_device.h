@@ -206,6 +206,41 @@ struct ProbeIter {
     }
 };
 
+// Probe record of one k-mer: everything the bucketed verify needs to regenerate the num_hashes indices with
+// 32-bit arithmetic only: x = h1 % d, y = h2 % d, z = ((h1+2)*h2 mod 2^64) % d, w = wrap-carry bits of the
+// 64-bit walk (bit i-3 set iff (h1+i)*h2 wrapped relative to (h1+i-1)*h2, i = 3..num_hashes-1).
+// Valid for d < 2^30 and num_hashes <= 35.
+__device__ __forceinline__ uint4 make_probe_record(uint64_t h1, uint64_t h2, const HashParams &hp) {
+    uint4 rec;
+    rec.x = mod_nbits(h1, hp);
+    rec.y = mod_nbits(h2, hp);
+    uint64_t r = (h1 + 2) * h2;
+    rec.z = mod_nbits(r, hp);
+    uint32_t cm = 0;
+    for (uint32_t i = 3; i < hp.num_hashes; ++i) {
+        uint64_t rn = r + h2;
+        cm |= (rn < r ? 1u : 0u) << (i - 3);
+        r = rn;
+    }
+    rec.w = cm;
+    return rec;
+}
+struct RecordIter {
+    uint32_t x, g, cm, i0;
+    __device__ __forceinline__ void init(const uint4 &rec) { i0 = rec.x; g = rec.y; x = rec.z; cm = rec.w; }
+    // i = 0, 1, 2, ... in order (wave-uniform loop counter); d < 2^30, dw = d - (2^64 mod d)
+    __device__ __forceinline__ uint32_t get(uint32_t i, uint32_t d, uint32_t dw) {
+        if (i == 0) return i0;
+        if (i == 1) return g;
+        if (i == 2) return x;
+        uint32_t t = x + g + (((cm >> (i - 3)) & 1u) ? dw : 0u);
+        t = min(t, t - d);
+        t = min(t, t - d);
+        x = t;
+        return x;
+    }
+};
+
 // `(threshold * n as f32).ceil() as usize` (query.rs:48): IEEE f32 multiply (no contraction possible: single op),
 // ceil, Rust's saturating float->int cast (NaN -> 0).
 __device__ __forceinline__ uint64_t need_kmers(float threshold, uint64_t n) {

@@ -101,6 +101,8 @@ struct pfq_tree {
     DevBuf<uint32_t> d_bucket, d_fail;  // bucket: cnt[n], off[n+1], cur[n]
     DevBuf<unsigned int> d_queue;
     DevBuf<uint8_t> d_allhit, d_seq;
+    DevBuf<uint4> d_recs;  // probe records of the bucketed path (16 B per read byte)
+    DevBuf<uint4> d_meta;  // resolved per-pair metadata for the record-driven verify
     DevBuf<uint64_t> d_off;
     DevBuf<unsigned long long> d_counts_snapshot;
     hipStream_t last_stream = nullptr;
@@ -386,15 +388,15 @@ int ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads) {
     HIP_TRY(t.d_sorted.ensure(cap));
     HIP_TRY(t.d_fail.ensure(cap));
     HIP_TRY(t.d_bucket.ensure(3 * t.leaves.size() + 2));
-    HIP_TRY(t.d_queue.ensure(16));  // (unused by the lock-step verify; kept zeroed)
+    HIP_TRY(t.d_queue.ensure(128));
     return PFQ_OK;
 }
 
 constexpr uint64_t BUCKET_MIN_READS = 1ull << 18;  // below this the bucketed pass cannot amortise warming the L2 slices
 constexpr uint64_t SLICE_TARGET_BYTES = 2560ull << 10;
 
-int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint64_t n_reads, float threshold,
-                 uint32_t flags, hipStream_t st, pfq_hits *hits) {
+int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint64_t n_reads, uint64_t total_bytes,
+                 float threshold, uint32_t flags, hipStream_t st, pfq_hits *hits) {
     if (t.root < 0) return fail(PFQ_ERR_STATE, "query on an empty tree");
     PFQ_TRY(build_layout(t));
     const bool want_hits = (flags & PFQ_WANT_HITS) != 0;
@@ -454,6 +456,16 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 a.pair_cap = t.d_pairs.n & ~31ull;  // whole reservations only (PAIR_CHUNK = 32)
                 a.pair_cursor = t.d_cursors.p + 1;
                 a.bucket_cnt = cnt;
+                // probe records: hash survivors once instead of once per slice (needs d < 2^30, <= 35 hashes, room)
+                uint4 *recs = nullptr;
+                uint64_t rec_budget = 64ull << 30;
+                if (const char *e = getenv("PFQ_RECORD_GB")) rec_budget = strtoull(e, nullptr, 10) << 30;
+                if (total_bytes && t.nbits < (1ull << 30) && t.num_hashes <= 35 && total_bytes * 16 <= rec_budget) {
+                    HIP_TRY(t.d_recs.ensure(total_bytes + 64));
+                    HIP_TRY(t.d_meta.ensure(t.d_pairs.n));
+                    recs = t.d_recs.p;
+                }
+                a.recs = recs;
                 uint32_t n_slices = 1;
                 uint64_t slice_target = SLICE_TARGET_BYTES;
                 if (const char *e = getenv("PFQ_SLICE_KB")) slice_target = strtoull(e, nullptr, 10) << 10;
@@ -461,11 +473,12 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 t.last_slices = n_slices;
                 HIP_TRY(hipMemsetAsync(cnt, 0, nl * 4, st));
                 HIP_TRY(hipMemsetAsync(t.d_fail.p, 0, t.d_fail.n * 4, st));
-                HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 16 * 4, st));
+                HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 128 * 4, st));
                 pfq::launch_classify(a, true, false, blocks, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
                 pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nl, st);
-                pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, t.d_sorted.p, 1024, st);
+                pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, t.d_sorted.p,
+                                           recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, 1024, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[2], st));
                 pfq::VerifyArgs v{};
                 v.hp = t.hp;
@@ -477,17 +490,24 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 v.sorted = t.d_sorted.p;
                 v.n_pairs_ptr = off + nl;
                 v.fail = t.d_fail.p;
+                v.recs = recs;
+                v.meta = t.d_meta.p;
                 v.n_slices = n_slices;
                 uint64_t sb = (t.n_words * 64 + n_slices - 1) / n_slices;
                 v.slice_bits = (uint32_t)((sb + 63) & ~63ull);
                 v.queue = t.d_queue.p;
                 // window of pairs in flight per slice = (blocks/8)*(8/n_slices)*4*chunk: about one leaf bucket
-                int vblocks = 1024;
-                v.chunk = 4;
+                int vblocks = 2048;
+                v.chunk = 1;
                 if (const char *e = getenv("PFQ_VERIFY_BLOCKS")) vblocks = std::max(8, atoi(e) & ~7);
                 if (const char *e = getenv("PFQ_VERIFY_DEBUG")) v.debug = (uint32_t)atoi(e);
                 if (const char *e = getenv("PFQ_VERIFY_CHUNK")) v.chunk = (uint32_t)std::max(1, atoi(e));
-                pfq::launch_verify(v, vblocks, st);
+                v.n_sub = 8;
+                if (const char *e = getenv("PFQ_VERIFY_SUB")) v.n_sub = (uint32_t)std::min(16, std::max(1, atoi(e)));
+                int vthreads = 256;
+                if (const char *e = getenv("PFQ_VERIFY_THREADS")) vthreads = std::min(1024, std::max(64, atoi(e) & ~63));
+                if (!recs) { vthreads = 256; vblocks = 1024; v.chunk = 4; }  // re-hash fallback kernel: 4-wave blocks
+                pfq::launch_verify(v, vblocks, vthreads, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[3], st));
                 pfq::FinalizeArgs f{};
                 f.hp = t.hp;
@@ -822,7 +842,7 @@ int pfq_tree_info(const pfq_tree *tree, pfq_info *out) {
     out->n_leaves = leaves_dfs(t).size();
     out->n_filters = t.filter_paths.size();
     out->device_bytes = t.d_bits.bytes() + t.d_S.bytes() + t.d_pairs.bytes() + t.d_sorted.bytes() + t.d_fail.bytes() +
-                        t.d_hit_pairs.bytes() + t.d_seq.bytes() + t.d_off.bytes();
+                        t.d_hit_pairs.bytes() + t.d_seq.bytes() + t.d_off.bytes() + t.d_recs.bytes();
     return PFQ_OK;
 }
 
@@ -849,10 +869,9 @@ void pfq_tree_close(pfq_tree *tree) {
 
 int pfq_query_batch_device(pfq_tree *tree, const uint8_t *d_seq, const uint64_t *d_offsets, uint64_t n_reads,
                            uint64_t total_bytes, float threshold, uint32_t flags, void *stream, pfq_hits *hits) {
-    (void)total_bytes;
     if (!tree || (n_reads && (!d_seq || !d_offsets))) return fail(PFQ_ERR_ARG, "null argument");
     PFQ_TRY(use_device(tree->device));
-    return query_device(*tree, d_seq, d_offsets, n_reads, threshold, flags, (hipStream_t)stream, hits);
+    return query_device(*tree, d_seq, d_offsets, n_reads, total_bytes, threshold, flags, (hipStream_t)stream, hits);
 }
 
 int pfq_query_batch(pfq_tree *tree, const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads, float threshold,
@@ -865,7 +884,7 @@ int pfq_query_batch(pfq_tree *tree, const uint8_t *seq, const uint64_t *offsets,
     HIP_TRY(t.d_off.ensure(n_reads + 1));
     if (total) HIP_TRY(hipMemcpy(t.d_seq.p, seq, total, hipMemcpyHostToDevice));
     if (n_reads) HIP_TRY(hipMemcpy(t.d_off.p, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice));
-    PFQ_TRY(query_device(t, t.d_seq.p, t.d_off.p, n_reads, threshold, flags, nullptr, hits));
+    PFQ_TRY(query_device(t, t.d_seq.p, t.d_off.p, n_reads, total, threshold, flags, nullptr, hits));
     HIP_TRY(hipStreamSynchronize(nullptr));
     return PFQ_OK;
 }

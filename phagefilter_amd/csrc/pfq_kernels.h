@@ -40,6 +40,7 @@ struct QueryArgs {
     uint64_t pair_cap;
     unsigned long long *pair_cursor;
     uint32_t *bucket_cnt;        // [n_leaves]
+    uint4 *recs;                 // probe records, indexed by (read byte offset + k-mer position), or nullptr
 };
 
 struct VerifyArgs {
@@ -50,10 +51,13 @@ struct VerifyArgs {
     const uint32_t *col_row;     // column -> filter row
     uint64_t n_words;
     const uint2 *sorted;         // (read, leaf) sorted by leaf
+    const uint4 *meta;           // per sorted pair: (read byte offset lo, hi, read length, filter row)
     const uint32_t *n_pairs_ptr; // &bucket_off[n_leaves]
     uint32_t *fail;              // [pair_cap]
     uint32_t n_slices, slice_bits;
-    unsigned int *queue;         // [n_slices] work cursors
+    unsigned int *queue;         // work cursors: [n_slices] (re-hash kernel) / [8 * n_sub] (record kernel)
+    uint32_t n_sub;              // sub-queues per XCD (record kernel)
+    const uint4 *recs;           // probe records written by k_classify<DEFER> (nullptr: re-hash per slice)
     uint32_t chunk;
     uint32_t debug;              // measurement switches (PFQ_VERIFY_DEBUG): 1 = probe leaf 0 only, 2 = no probe loads
 };
@@ -76,8 +80,9 @@ struct FinalizeArgs {
 void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int blocks, hipStream_t st);
 void launch_bucket_scan(const uint32_t *bucket_cnt, uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t n, hipStream_t st);
 void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
-                           const uint32_t *bucket_off, uint32_t *bucket_cur, uint2 *sorted, int blocks, hipStream_t st);
-void launch_verify(const VerifyArgs &a, int blocks, hipStream_t st);
+                           const uint32_t *bucket_off, uint32_t *bucket_cur, uint2 *sorted, uint4 *meta,
+                           const uint64_t *read_off, const uint32_t *col_row, int blocks, hipStream_t st);
+void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st);
 void launch_finalize(const FinalizeArgs &a, hipStream_t st);
 
 void launch_insert(const HashParams &hp, const uint8_t *d_genomes, const uint64_t *d_goff, uint32_t n_genomes,

@@ -63,12 +63,11 @@ __device__ __forceinline__ bool verify_column(BlockLds &lds, uint32_t wave, cons
 // Probes 0 and 1 of the first SCREEN_ROUNDS*slots k-mers: every row is one line of S.  A leaf survives only if all
 // probed bits are set (necessary for passing at need == n).
 __device__ __forceinline__ uint32_t screen_all(BlockLds &lds, uint32_t wave, const QueryArgs &a, const ReadCtx &rc,
-                                               uint32_t colmask) {
+                                               uint32_t colmask, uint64_t &h1, uint64_t &h2) {
     const uint32_t lane = lane_id(), rw = a.rw, slots = 64u >> a.rw_log2;
     const uint32_t word = lane & (rw - 1u), slot = lane >> a.rw_log2;
     uint32_t cnt = (uint32_t)(rc.n < WIN_KMERS ? rc.n : WIN_KMERS);
     stage_window(lds, wave, rc.read, 0, cnt, a.hp.k);
-    uint64_t h1, h2;
     kmer_hashes(lds, wave, lane, cnt, lane < cnt, a.hp, h1, h2);
     uint32_t i0 = mod_nbits(h1, a.hp), i1 = mod_nbits(h2, a.hp);
     uint32_t v0[SCREEN_ROUNDS], v1[SCREEN_ROUNDS];
@@ -184,8 +183,12 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
 
         // The AND-frontier is only valid when no miss is tolerated; (n as f32) rounds for n >= 2^24, so even at
         // theta == 1 a read can have maxmiss > 0: such reads are certified against every leaf instead.
-        uint32_t live = COUNTS ? screen_counts(lds, wave, a, rc, colmask)
-                               : (rc.maxmiss == 0 ? screen_all(lds, wave, a, rc, colmask) : colmask);
+        bool prepared = false, have_w0 = false;
+        uint64_t w0_h1 = 0, w0_h2 = 0;  // hashes of the first window when the AND-frontier computed them
+        uint32_t live;
+        if (COUNTS) live = screen_counts(lds, wave, a, rc, colmask);
+        else if (rc.maxmiss == 0) { live = screen_all(lds, wave, a, rc, colmask, w0_h1, w0_h2); have_w0 = true; }
+        else live = colmask;
 
         while (true) {
             uint64_t b = ballot64(live != 0 && slot == 0);
@@ -213,6 +216,19 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
                     }
                     ++pair_used;
                     ++st_def;
+                    if (a.recs && !prepared) {  // hash the read once; every slice of the verify reuses the records
+                        prepared = true;
+                        for (uint64_t base = 0; base < rc.n; base += WIN_KMERS) {
+                            uint32_t cnt = (uint32_t)((rc.n - base) < WIN_KMERS ? (rc.n - base) : WIN_KMERS);
+                            uint64_t h1 = w0_h1, h2 = w0_h2;
+                            if (base != 0 || !have_w0) {
+                                stage_window(lds, wave, rc.read, base, cnt, a.hp.k);
+                                kmer_hashes(lds, wave, lane, cnt, lane < cnt, a.hp, h1, h2);
+                            }
+                            uint4 rec = make_probe_record(h1, h2, a.hp);
+                            if (lane < cnt) a.recs[o0 + base + lane] = rec;
+                        }
+                    }
                     continue;
                 }
                 // no room left in the pair buffer: certify inline below (results stay exact)
@@ -284,20 +300,29 @@ void launch_bucket_scan(const uint32_t *bucket_cnt, uint32_t *bucket_off, uint32
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(64), 0, st, bucket_cnt, bucket_off, bucket_cur, n);
 }
 
+// Scatter into leaf order; `meta` gets everything the record-driven verify needs about a pair in one 16-byte
+// entry (read byte offset, read length, filter row) so that kernel has no dependent metadata loads.
 __global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr,
-                                                        uint64_t pair_cap, const uint32_t *off, uint32_t *cur, uint2 *sorted) {
+                                                        uint64_t pair_cap, const uint32_t *off, uint32_t *cur, uint2 *sorted,
+                                                        uint4 *meta, const uint64_t *read_off, const uint32_t *col_row) {
     uint64_t n = *n_pairs_ptr;
     if (n > pair_cap) n = pair_cap;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint2 p = pairs[i];
         if (p.y == 0xffffffffu) continue;  // voided slot of a partially used reservation
-        uint32_t pos = atomicAdd(&cur[p.y], 1u);
-        sorted[off[p.y] + pos] = p;
+        uint32_t pos = off[p.y] + atomicAdd(&cur[p.y], 1u);
+        sorted[pos] = p;
+        if (meta) {
+            uint64_t o0 = read_off[p.x], L = read_off[p.x + 1] - o0;
+            meta[pos] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)L, col_row[p.y]);
+        }
     }
 }
 void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
-                           const uint32_t *bucket_off, uint32_t *bucket_cur, uint2 *sorted, int blocks, hipStream_t st) {
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, pairs, n_pairs_ptr, pair_cap, bucket_off, bucket_cur, sorted);
+                           const uint32_t *bucket_off, uint32_t *bucket_cur, uint2 *sorted, uint4 *meta,
+                           const uint64_t *read_off, const uint32_t *col_row, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, pairs, n_pairs_ptr, pair_cap, bucket_off, bucket_cur,
+                       sorted, meta, read_off, col_row);
 }
 
 // ---- K2 for bucketed survivors: L2-resident filter slices ------------------------------------------------------------
@@ -359,8 +384,102 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs a) {
         }
     }
 }
-void launch_verify(const VerifyArgs &a, int blocks, hipStream_t st) {
-    hipLaunchKernelGGL(k_verify, dim3(blocks), dim3(256), 0, st, a);
+// Record-driven variant: the probe records written by k_classify<DEFER> replace all hashing.  Built for
+// memory-level parallelism: per pair, the records of three windows and their 3*num_hashes probes are independent
+// loads issued back to back; the item loop is software-pipelined (the queue pull for item t+2 and the metadata
+// load for item t+1 are in flight while item t is probed; one barrier per item on a double-buffered LDS slot).
+// One queue per XCD (8): XCD q serves slice q % n_slices and, of that slice's items, those congruent to
+// q / n_slices modulo the XCDs per slice; XCDs never share a queue (each has its own L2, so they need not move
+// in step).  A block whose own queue is drained helps the others.
+__global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
+    __shared__ uint32_t s_item[2];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t n_pairs = *a.n_pairs_ptr;
+    // an item = (waves per block) x chunk consecutive pairs, pulled with ONE queue atomic (a same-address returning
+    // atomic costs ~90 ns at the memory side, so items must be large) while the pairs in flight per XCD
+    // (blocks per XCD x item) stay at about one leaf's share
+    const uint32_t per_wave = a.chunk < 64u ? a.chunk : 64u, item_pairs = per_wave * (blockDim.x >> 6);
+    const uint64_t n_items = (n_pairs + item_pairs - 1) / item_pairs;
+    const uint32_t home = xcc_id() & 7u, groups = 8u / a.n_slices;
+    const uint32_t d = (uint32_t)a.hp.nbits, dw = d - (uint32_t)a.hp.w64, k = a.hp.k;
+
+    auto load_meta = [&](uint64_t it) -> uint4 {
+        const uint64_t e = it * item_pairs + (uint64_t)wave * per_wave + lane;
+        return (it < n_items && lane < per_wave && e < n_pairs) ? a.meta[e] : make_uint4(0, 0, 0, 0);
+    };
+
+    // Every XCD's item sequence is dealt round-robin to n_sub sub-queues (own counter each) so that no counter
+    // sees more than a few tens of thousands of pulls per launch; the sub-queues of an XCD advance at the same
+    // average rate, so the XCD still works on one leaf's share at a time.
+    const uint32_t n_sub = a.n_sub, home_sub = (blockIdx.x >> 3) % n_sub;
+    for (uint32_t att = 0; att < 8u * n_sub; ++att) {
+        const uint32_t sub = (home_sub + att) % n_sub, q = (home + att / n_sub) & 7u;
+        const uint32_t s = q % a.n_slices, part = q / a.n_slices;
+        const uint32_t lo = s * a.slice_bits;
+        unsigned int *qctr = &a.queue[q * n_sub + sub];
+        const uint64_t stride = (uint64_t)groups * n_sub, first = (uint64_t)sub * groups + part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_item[0] = atomicAdd(qctr, 1u);
+            s_item[1] = atomicAdd(qctr, 1u);
+        }
+        __syncthreads();
+        uint64_t it_cur = (uint64_t)s_item[0] * stride + first, it_nxt = (uint64_t)s_item[1] * stride + first;
+        __syncthreads();
+        uint4 meta_cur = load_meta(it_cur);
+        uint32_t buf = 0;
+        while (it_cur < n_items) {
+            uint32_t pend = 0;
+            if (threadIdx.x == 0) pend = atomicAdd(qctr, 1u);  // item t+2
+            const uint4 meta_nxt = load_meta(it_nxt);                   // item t+1
+            const uint64_t e0 = it_cur * item_pairs + (uint64_t)wave * per_wave;
+            const uint32_t W = e0 >= n_pairs ? 0u : (uint32_t)(e0 + per_wave < n_pairs ? per_wave : n_pairs - e0);
+            for (uint32_t j = 0; j < W; ++j) {
+                const uint64_t o0 = ((uint64_t)bcast_u32(meta_cur.y, j) << 32) | bcast_u32(meta_cur.x, j);
+                const uint64_t n = (uint64_t)bcast_u32(meta_cur.z, j) - k + 1;  // candidates always have n >= 1
+                const uint4 *rp = a.recs + o0;
+                const uint32_t row = (a.debug & 1u) ? 0u : bcast_u32(meta_cur.w, j);
+                const uint32_t *bm = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)row * a.n_words);
+                bool miss = false;
+                for (uint64_t g0 = 0; g0 < n; g0 += 3 * WIN_KMERS) {
+                    uint4 rec[3];
+                    bool valid[3];
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) {
+                        const uint64_t qq = g0 + 64u * w + lane;
+                        valid[w] = qq < n;
+                        rec[w] = (valid[w] && !(a.debug & 8u)) ? rp[qq] : make_uint4(lane, (uint32_t)qq, 7u, 0u);
+                    }
+                    uint32_t ok = 1;
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) {
+                        RecordIter rit;
+                        rit.init(rec[w]);
+#pragma unroll 5
+                        for (uint32_t i = 0; i < a.hp.num_hashes; ++i) {
+                            const uint32_t idx = rit.get(i, d, dw);
+                            const bool in = valid[w] && (idx - lo) < a.slice_bits && !(a.debug & 2u);
+                            const uint32_t v = in ? bm[idx >> 5] : ~0u;
+                            ok &= (v >> (idx & 31u)) | (a.debug & 1u);
+                        }
+                    }
+                    miss = miss || !(ok & 1u);
+                }
+                if (ballot64(miss) && lane == 0) a.fail[e0 + j] = 1u;
+            }
+            if (threadIdx.x == 0) s_item[buf] = pend;
+            __syncthreads();
+            const uint64_t it_new = (uint64_t)s_item[buf] * stride + first;
+            buf ^= 1u;
+            it_cur = it_nxt;
+            meta_cur = meta_nxt;
+            it_nxt = it_new;
+        }
+    }
+}
+void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st) {
+    if (a.recs) hipLaunchKernelGGL(k_verify_rec, dim3(blocks), dim3(threads), 0, st, a);
+    else hipLaunchKernelGGL(k_verify, dim3(blocks), dim3(256), 0, st, a);
 }
 
 // One block per leaf bucket: pairs that no slice failed are hits (mapped_reads += |pass|, query.rs:143).

@@ -151,8 +151,14 @@ def test_query_matches_oracle(gpu, n_genomes, k, nbits, h):
     for thr in (1.0, 0.0, 0.3, 0.5, 0.75, 0.999, 1.5, -1.0, float("nan")):
         st = check_query(gt, ot, reads, thr, path=0)
         assert st.path == 0
-    st = check_query(gt, ot, reads, 1.0, path=1)                   # bucketed: screen + L2-sliced verify
+    st = check_query(gt, ot, reads, 1.0, path=1)                   # bucketed: screen + records + L2-sliced verify
     assert st.path == 1
+    os.environ["PFQ_RECORD_GB"] = "0"                              # bucketed without probe records (re-hash per slice)
+    try:
+        st = check_query(gt, ot, reads, 1.0, path=1)
+        assert st.path == 1
+    finally:
+        del os.environ["PFQ_RECORD_GB"]
     gt.close()
 
 
