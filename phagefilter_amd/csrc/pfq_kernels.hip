@@ -6,8 +6,9 @@
 //                emptiness (subtree/leaf pruning), and surviving leaves get the full certificate of
 //                query_passes (query.rs:38-49): lanes = k-mers, `__ballot` of "all probed bits set",
 //                `__popcll` accumulate, compare with need.  DEFER variant hands survivors to the bucketed pass.
-//   k_verify     the certificate for survivors bucketed by leaf: every XCD keeps one slice of the current
-//                leaf's node-major filter hot in its own L2 and checks only the probes that fall in its slice.
+//   k_verify_rec the certificate for survivors bucketed by leaf: every XCD keeps one slice of the current
+//                leaf's node-major filter hot in its own L2 and checks only the probes that fall in its slice;
+//                indices come from the probe records k_classify<DEFER> wrote (k_verify: same, re-hashing).
 //   k_insert / k_union / k_superset / k_transpose   database construction on the device.
 //
 // Reference semantics: query.rs:38-158, bloom_filter.rs:312-332, hash_iter.rs:13-45, file_parser.rs:114-148.
