@@ -51,10 +51,17 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal knobs (not used by the driver): PFQ_BENCH_SAME_GPU=1 puts every rank on device 0 and
+    # PFQ_BENCH_BACKEND=gloo replaces RCCL, so the N > 1 code path can be exercised on a one-GPU box.
+    dev_index = 0 if os.environ.get("PFQ_BENCH_SAME_GPU") == "1" else local_rank
+    backend = os.environ.get("PFQ_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from phagefilter_amd import BloomTree, _ffi
     from phagefilter_amd.dist import all_reduce_counts
@@ -68,7 +75,7 @@ def main() -> None:
     _ffi.check(L.pfq_synth_genomes_device(genomes.data_ptr(), n_g, glen, GENOME_SEED, None))
     torch.cuda.synchronize()
     tree = BloomTree.build_balanced_device(genomes.data_ptr(), glen, n_g, ids, K, NBITS, NUM_HASHES, SEEDS[0], SEEDS[1],
-                                           0.001, 5000000, device=local_rank)
+                                           0.001, 5000000, device=dev_index)
     tree.set_path(args.path)
 
     # ---- reads: every (step, rank) gets its own slice of the global read index space, resident in HBM
@@ -97,7 +104,10 @@ def main() -> None:
 
     def barrier() -> None:
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
 
     # ---- timed region: exactly K steps + the single all-reduce of per-genome counts
     tree.profile_begin(args.steps)

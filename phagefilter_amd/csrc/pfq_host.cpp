@@ -466,6 +466,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                     recs = t.d_recs.p;
                 }
                 a.recs = recs;
+                a.rec_cap = recs ? t.d_recs.n : 0;
                 uint32_t n_slices = 1;
                 uint64_t slice_target = SLICE_TARGET_BYTES;
                 if (const char *e = getenv("PFQ_SLICE_KB")) slice_target = strtoull(e, nullptr, 10) << 10;

@@ -41,6 +41,7 @@ struct QueryArgs {
     unsigned long long *pair_cursor;
     uint32_t *bucket_cnt;        // [n_leaves]
     uint4 *recs;                 // probe records, indexed by (read byte offset + k-mer position), or nullptr
+    uint64_t rec_cap;            // entries in recs (reads whose records would not fit are certified inline)
 };
 
 struct VerifyArgs {

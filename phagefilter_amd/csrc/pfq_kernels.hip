@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             uint32_t col = (uint32_t)src * 32u + bit;
             if ((int)lane == src) live &= ~(1u << bit);
             ++st_cand;
-            if (DEFER) {
+            if (DEFER && (!a.recs || o0 + rc.n <= a.rec_cap)) {
                 if (pair_used == PAIR_CHUNK) {  // wave-uniform
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(a.pair_cursor, (unsigned long long)PAIR_CHUNK);

@@ -311,3 +311,92 @@ def test_config2_shape_64_leaves_k21(gpu):
     # every positive read hits (at least) its source leaf: about half of the reads
     assert 0.49 * n_reads < len(ohits) < 0.52 * n_reads
     gt.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json full-size configurations
+# ---------------------------------------------------------------------------------------------------------------
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15))
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def _read_plan(seed, first, count, n_genomes):
+    """(is_positive, leaf) of reads first..first+count from the generator's definition (oracle/pfq_oracle.c)."""
+    with np.errstate(over="ignore"):
+        r = np.arange(first, first + count, dtype=np.uint64)
+        w0 = _splitmix64(_splitmix64(np.uint64(seed)) + np.uint64(8) * r)
+    return (w0 & np.uint64(1)).astype(bool), ((w0 >> np.uint64(8)) % np.uint64(n_genomes)).astype(np.int64)
+
+
+def test_config2_full_size_1m_reads_64_leaves(gpu):
+    """BASELINE config 2 at its real size: 1 M synthetic 150 bp reads vs a 64-leaf SBT, k=21, nbits=71 887 936,
+    10 hashes, 50 kbp genomes; per-leaf counts and every per-read hit set equal the oracle's, on both paths."""
+    import torch
+    from phagefilter_amd import _ffi
+    n_g, glen, k, h, nbits, n_reads = 64, 50000, 21, 10, 71887936, 1000000
+    seeds = (0x0123456789ABCDEF, 0xFEDCBA9876543210)
+    genomes_np = np.stack([np.frombuffer(orc.synth_genome(0x5EED0000 + i, glen), dtype=np.uint8) for i in range(n_g)])
+    ids = [f"G{i:05d}" for i in range(n_g)]
+    ot = orc.build_balanced_tree([g.tobytes() for g in genomes_np], ids, k, nbits, h, *seeds)
+    dg = torch.from_numpy(genomes_np.reshape(-1).copy()).cuda()
+    gt = BloomTree.build_balanced_device(dg.data_ptr(), glen, n_g, ids, k, nbits, h, *seeds)
+    for v in (0, 1, 63, 126):
+        assert np.array_equal(gt.node_filter(v), ot.bits[v])
+    reads_np = orc.synth_reads(0x5EED1234, 0, n_reads, 150, genomes_np, glen)
+    seq = np.concatenate([reads_np.reshape(-1), np.zeros(16, dtype=np.uint8)])
+    off = np.arange(n_reads + 1, dtype=np.uint64) * 150
+    ohits, _, _ = orc.query_batch_packed(ot, seq, off, 1.0, threads=min(32, os.cpu_count() or 8))
+    want = np.array(oracle_hits(ot, ohits), dtype=np.int64).reshape(-1, 2)
+    for path in (1, 0):
+        gt.reset_counts()
+        gt.set_path(path)
+        offs, leaves = gt.query_packed(seq, off, 1.0, want_hits=True)
+        assert gt.get_leaf_counts() == ot.leaf_counts()
+        got = np.stack([np.repeat(np.arange(n_reads), np.diff(offs).astype(np.int64)), leaves.astype(np.int64)], 1)
+        assert np.array_equal(got, want)
+    pos, leaf = _read_plan(0x5EED1234, 0, n_reads, n_g)
+    assert np.array_equal(np.unique(want[:, 0]), np.nonzero(pos)[0])          # exactly the positive reads hit
+    gt.close()
+
+
+def test_config3_properties_1024_leaves(gpu):
+    """BASELINE config 3/4 shape (1024-leaf SBT, full parameters) through size-independent properties: every
+    positive read hits its source leaf; counts are additive over a partition of the reads (what read sharding across
+    GPUs relies on) and independent of the query path and of the block size; false-positive leaves are rare."""
+    import torch
+    from phagefilter_amd import _ffi
+    L = _ffi.lib()
+    n_g, glen, k, h, nbits, n_reads = 1024, 50000, 21, 10, 71887936, 4 * 1024 * 1024
+    ids = [f"G{i:05d}" for i in range(n_g)]
+    dg = torch.empty(n_g * glen, dtype=torch.uint8, device="cuda")
+    _ffi.check(L.pfq_synth_genomes_device(dg.data_ptr(), n_g, glen, 0x5EED0000, None))
+    torch.cuda.synchronize()
+    gt = BloomTree.build_balanced_device(dg.data_ptr(), glen, n_g, ids, k, nbits, h, 0x0123456789ABCDEF, 0xFEDCBA9876543210)
+    info = gt.info()
+    assert (info.n_nodes, info.n_leaves, info.superset_verified) == (2047, 1024, 1)
+    dr = torch.empty(n_reads * 150 + 64, dtype=torch.uint8, device="cuda")
+    _ffi.check(L.pfq_synth_reads_device(dr.data_ptr(), 0, n_reads, 150, dg.data_ptr(), glen, n_g, 0x5EED1234, None))
+    off = torch.arange(n_reads + 1, dtype=torch.int64, device="cuda") * 150
+    torch.cuda.synchronize()
+    pos, leaf = _read_plan(0x5EED1234, 0, n_reads, n_g)
+    expect = np.bincount(leaf[pos], minlength=n_g)
+
+    def counts(path, lo, hi):
+        gt.reset_counts()
+        gt.set_path(path)
+        gt.query_device(dr.data_ptr() + lo * 150, off.data_ptr(), hi - lo, (hi - lo) * 150, 1.0, 0)
+        torch.cuda.synchronize()
+        return np.array([c for _, c in gt.get_leaf_counts()], dtype=np.int64)
+
+    whole = counts(1, 0, n_reads)
+    assert (whole >= expect).all()                                   # every positive read hits its source leaf
+    assert 0 <= int(whole.sum() - expect.sum()) <= n_reads // 100000  # Bloom false-positive leaves are rare
+    half = n_reads // 2
+    assert np.array_equal(counts(1, 0, half) + counts(1, half, n_reads), whole)          # additive over shards
+    thirds = [0, 1000003, 2500000, n_reads]
+    assert np.array_equal(sum(counts(0, a, b) for a, b in zip(thirds, thirds[1:])), whole)  # path/block independent
+    assert np.array_equal(counts(1, 0, n_reads), whole)                                  # idempotent
+    gt.close()
