@@ -46,6 +46,8 @@ typedef struct pfq_info {
     uint64_t seed1, seed2;
     uint64_t n_nodes, n_leaves, n_filters;
     uint64_t device_bytes; /* HBM held by this tree */
+    uint64_t shard_first_leaf; /* subtree shards: position of this shard's first leaf in the whole tree's leaf order */
+    uint64_t tree_leaves;      /* leaves of the whole tree (== n_leaves unless this is a subtree shard) */
 } pfq_info;
 
 /* Per-read results of one pfq_query_batch call: CSR read -> leaf indices (indices into pfq_leaf_counts'
@@ -65,6 +67,15 @@ typedef struct pfq_hits {
  * by their relative path exactly like the cache), uploads them, verifies parent ⊇ child per edge and builds
  * the device layout.  `device` = HIP device ordinal. */
 int pfq_tree_open(const char *db_dir, int device, pfq_tree **out);
+
+/* Subtree shard of a database, for trees larger than one GPU's HBM (BASELINE config 5): the shards
+ * are the nodes of the depth-`depth` frontier in left-to-right order (nodes at that depth, plus leaves above it).
+ * Shard `index` keeps that node, everything below it and the chain of its ancestors, each reduced to the child on
+ * the path; only those .bf files are read.  Every rank classifies ALL reads against its shard; the shards' leaf
+ * ranges are disjoint and contiguous in the whole tree's leaf order (pfq_info.shard_first_leaf), so the whole
+ * job's counts are the concatenation of the shards' counts.  Ancestors that are not verified supersets become
+ * guard columns, so results equal the reference's whole-tree traversal. */
+int pfq_tree_open_subtree(const char *db_dir, int device, uint64_t depth, uint64_t index, pfq_tree **out);
 
 /* Synthetic balanced SBT built on the device: leaf i = all canonical k-mers of genome i
  * (what bloom_tree.rs:154-168 inserts), internal = OR of children (bloom_tree.rs:238-239), complete-as-possible

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libpfq.so")
 
 # every symbol include/pfq.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "pfq_tree_open", "pfq_tree_build_balanced", "pfq_tree_build_balanced_device", "pfq_tree_save", "pfq_tree_info",
+    "pfq_tree_open", "pfq_tree_open_subtree", "pfq_tree_build_balanced", "pfq_tree_build_balanced_device", "pfq_tree_save", "pfq_tree_info",
     "pfq_tree_prune", "pfq_tree_close", "pfq_query_batch", "pfq_query_batch_device", "pfq_leaf_counts",
     "pfq_save_leaf_counts", "pfq_leaf_counts_export", "pfq_leaf_counts_import", "pfq_leaf_counts_reset",
     "pfq_last_stats", "pfq_set_path", "pfq_profile_begin", "pfq_profile_end", "pfq_debug_kmer_indices", "pfq_debug_node_filter", "pfq_synth_genomes_device",
@@ -29,7 +29,7 @@ class Info(C.Structure):
                 ("largest_expected_genome", C.c_uint32), ("false_pos_rate", C.c_float),
                 ("superset_verified", C.c_uint32), ("seed1", C.c_uint64), ("seed2", C.c_uint64),
                 ("n_nodes", C.c_uint64), ("n_leaves", C.c_uint64), ("n_filters", C.c_uint64),
-                ("device_bytes", C.c_uint64)]
+                ("device_bytes", C.c_uint64), ("shard_first_leaf", C.c_uint64), ("tree_leaves", C.c_uint64)]
 
 
 class Hits(C.Structure):
@@ -63,6 +63,7 @@ def lib() -> C.CDLL:
     L.pfq_last_error.restype = C.c_char_p
     L.pfq_version.restype = C.c_char_p
     L.pfq_tree_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.pfq_tree_open_subtree.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.pfq_tree_build_balanced.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_char_p), C.c_uint64, C.c_uint64,
                                           C.c_uint32, C.c_uint64, C.c_uint64, C.c_float, C.c_uint32, C.c_int,
                                           C.POINTER(vp)]

@@ -23,7 +23,7 @@ struct HashParams {
 
 constexpr uint32_t KMAX = 64;                        // supported k-mer length on the device path
 constexpr uint32_t WIN_KMERS = 64;                   // k-mers per window = lanes per wave
-constexpr uint32_t WIN_PAD = 8;                      // slack so aligned dword over-reads stay inside the window
+constexpr uint32_t WIN_PAD = 8;                      // slack so aligned dword over-reads stay inside the buffer
 constexpr uint32_t WIN_BYTES = 160;                  // >= WIN_PAD + (WIN_KMERS + KMAX - 1) + WIN_PAD, dword multiple
 constexpr uint32_t WIN_DWORDS = WIN_BYTES / 4;
 constexpr uint32_t WAVES_PER_BLOCK = 4;
@@ -34,6 +34,8 @@ constexpr uint64_t FX_SEED2 = 0x13198a2e03707344ull;
 constexpr uint64_t FX_PTZC = 0xa4093822299f31d0ull;
 
 // LDS of one block: per-wave forward / reverse-complement windows + the shared complement table.
+// (Staging a whole 192- or 448-k-mer segment of the read at once was tried: it removes global round trips for
+// 150 bp reads but costs ~30 VGPRs in k_classify (occupancy 6 -> 4 waves/SIMD) and measured 6 % slower.)
 struct BlockLds {
     uint32_t win[WAVES_PER_BLOCK][2][WIN_DWORDS];
     uint8_t comp[256];
@@ -87,13 +89,18 @@ __device__ __forceinline__ void stage_window(BlockLds &lds, uint32_t wave, const
     uint8_t *fwd = reinterpret_cast<uint8_t *>(lds.win[wave][0]);
     uint8_t *rc = reinterpret_cast<uint8_t *>(lds.win[wave][1]);
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (uint32_t j = lane; j < WIN_KMERS + KMAX - 1; j += 64) {
-        if (j < W) {
-            uint8_t b = read[base + j];
-            fwd[WIN_PAD + j] = b;
-            rc[WIN_PAD + (W - 1 - j)] = lds.comp[b];
-        }
+    // both byte loads are issued before either is consumed (W <= 127: two bytes per lane)
+    const bool v0 = lane < W, v1 = lane + 64u < W;
+    uint8_t b0 = 0, b1 = 0;
+    if (v0) b0 = read[base + lane];
+    if (v1) b1 = read[base + lane + 64u];
+    if (v0) {
+        fwd[WIN_PAD + lane] = b0;
+        rc[WIN_PAD + (W - 1 - lane)] = lds.comp[b0];
+    }
+    if (v1) {
+        fwd[WIN_PAD + lane + 64u] = b1;
+        rc[WIN_PAD + (W - 1 - lane - 64u)] = lds.comp[b1];
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -175,6 +182,7 @@ __device__ __forceinline__ uint32_t mod_nbits(uint64_t r, const HashParams &hp) 
 struct ProbeIter {
     uint64_t r, h2;
     uint32_t x, g, i0;
+    // after init: i0 = index 0, g = index 1, x = index 2
     __device__ __forceinline__ void init(uint64_t h1, uint64_t h2_, const HashParams &hp) {
         h2 = h2_;
         i0 = mod_nbits(h1, hp);
@@ -182,11 +190,8 @@ struct ProbeIter {
         r = (h1 + 2) * h2_;
         x = mod_nbits(r, hp);
     }
-    // Must be called with i = 0, 1, 2, ... in order; i is wave-uniform (a loop counter).
-    __device__ __forceinline__ uint32_t get(uint32_t i, const HashParams &hp) {
-        if (i == 0) return i0;
-        if (i == 1) return g;
-        if (i == 2) return x;
+    // index 3, 4, ... on successive calls
+    __device__ __forceinline__ uint32_t step(const HashParams &hp) {
         uint64_t rn = r + h2;
         bool carry = rn < r;
         r = rn;
@@ -205,6 +210,15 @@ struct ProbeIter {
         return x;
     }
 };
+
+// Calls f(index) for the num_hashes probe indices of a k-mer in order (hash_iter.rs:13-27).
+template <typename F>
+__device__ __forceinline__ void for_each_probe(ProbeIter &it, const HashParams &hp, F &&f) {
+    f(it.i0);
+    if (hp.num_hashes > 1) f(it.g);
+    if (hp.num_hashes > 2) f(it.x);
+    for (uint32_t i = 3; i < hp.num_hashes; ++i) f(it.step(hp));
+}
 
 // Probe record of one k-mer: everything the bucketed verify needs to regenerate the num_hashes indices with
 // 32-bit arithmetic only: x = h1 % d, y = h2 % d, z = ((h1+2)*h2 mod 2^64) % d, w = wrap-carry bits of the
@@ -227,13 +241,12 @@ __device__ __forceinline__ uint4 make_probe_record(uint64_t h1, uint64_t h2, con
 }
 struct RecordIter {
     uint32_t x, g, cm, i0;
+    // after init: i0 = index 0, g = index 1, x = index 2
     __device__ __forceinline__ void init(const uint4 &rec) { i0 = rec.x; g = rec.y; x = rec.z; cm = rec.w; }
-    // i = 0, 1, 2, ... in order (wave-uniform loop counter); d < 2^30, dw = d - (2^64 mod d)
-    __device__ __forceinline__ uint32_t get(uint32_t i, uint32_t d, uint32_t dw) {
-        if (i == 0) return i0;
-        if (i == 1) return g;
-        if (i == 2) return x;
-        uint32_t t = x + g + (((cm >> (i - 3)) & 1u) ? dw : 0u);
+    // index 3, 4, ... on successive calls; d < 2^30, dw = d - (2^64 mod d)
+    __device__ __forceinline__ uint32_t step(uint32_t d, uint32_t dw) {
+        uint32_t t = x + g + ((cm & 1u) ? dw : 0u);
+        cm >>= 1;
         t = min(t, t - d);
         t = min(t, t - d);
         x = t;

@@ -84,6 +84,8 @@ struct pfq_tree {
     std::vector<std::string> filter_paths;
     std::vector<uint8_t> edge_ok;  // per node: parent(v) ⊇ v verified
     bool superset_all = true;
+    uint64_t shard_first_leaf = 0, tree_leaves = 0;  // subtree shards (pfq_tree_open_subtree)
+    bool is_shard = false;
     pfq::HashParams hp{};
     // ---- device: node-major filters
     DevBuf<uint64_t> d_bits;
@@ -272,8 +274,19 @@ int verify_supersets(pfq_tree &t) {
     t.superset_all = true;
     std::vector<uint32_t> edges;
     std::vector<int32_t> edge_node;
+    std::vector<uint8_t> reach(t.nodes.size(), 0);
+    if (t.root >= 0) {
+        std::vector<int32_t> st{t.root};
+        while (!st.empty()) {
+            int32_t v = st.back();
+            st.pop_back();
+            reach[v] = 1;
+            if (t.nodes[v].left >= 0) st.push_back(t.nodes[v].left);
+            if (t.nodes[v].right >= 0) st.push_back(t.nodes[v].right);
+        }
+    }
     for (size_t v = 0; v < t.nodes.size(); ++v)
-        if (t.nodes[v].parent >= 0 && t.nodes[t.nodes[v].parent].filter != t.nodes[v].filter) {
+        if (reach[v] && t.nodes[v].parent >= 0 && t.nodes[t.nodes[v].parent].filter != t.nodes[v].filter) {
             edges.push_back(t.nodes[t.nodes[v].parent].filter);
             edges.push_back(t.nodes[v].filter);
             edge_node.push_back((int32_t)v);
@@ -498,14 +511,13 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 v.slice_bits = (uint32_t)((sb + 63) & ~63ull);
                 v.queue = t.d_queue.p;
                 // window of pairs in flight per slice = (blocks/8)*(8/n_slices)*4*chunk: about one leaf bucket
-                int vblocks = 2048;
+                int vblocks = 512;
                 v.chunk = 1;
                 if (const char *e = getenv("PFQ_VERIFY_BLOCKS")) vblocks = std::max(8, atoi(e) & ~7);
-                if (const char *e = getenv("PFQ_VERIFY_DEBUG")) v.debug = (uint32_t)atoi(e);
                 if (const char *e = getenv("PFQ_VERIFY_CHUNK")) v.chunk = (uint32_t)std::max(1, atoi(e));
                 v.n_sub = 8;
                 if (const char *e = getenv("PFQ_VERIFY_SUB")) v.n_sub = (uint32_t)std::min(16, std::max(1, atoi(e)));
-                int vthreads = 256;
+                int vthreads = 512;
                 if (const char *e = getenv("PFQ_VERIFY_THREADS")) vthreads = std::min(1024, std::max(64, atoi(e) & ~63));
                 if (!recs) { vthreads = 256; vblocks = 1024; v.chunk = 4; }  // re-hash fallback kernel: 4-wave blocks
                 pfq::launch_verify(v, vblocks, vthreads, st);
@@ -682,7 +694,7 @@ extern "C" {
 const char *pfq_last_error(void) { return g_err.c_str(); }
 const char *pfq_version(void) { return "libpfq 0.1 (gfx950)"; }
 
-int pfq_tree_open(const char *db_dir, int device, pfq_tree **out) {
+static int open_impl(const char *db_dir, int device, bool shard, uint64_t shard_depth, uint64_t shard_index, pfq_tree **out) {
     if (!db_dir || !out) return fail(PFQ_ERR_ARG, "null argument");
     *out = nullptr;
     PFQ_TRY(use_device(device));
@@ -702,9 +714,60 @@ int pfq_tree_open(const char *db_dir, int device, pfq_tree **out) {
     t->seed1 = c.u64();
     t->seed2 = c.u64();
     if (!c.ok || c.p != c.n) return fail(PFQ_ERR_FORMAT, "tree.bin: truncated or trailing bytes");
+    t->tree_leaves = leaves_dfs(*t).size();
+    std::vector<uint8_t> reachable(t->nodes.size(), 1);
+    if (shard) {
+        if (t->root < 0) return fail(PFQ_ERR_STATE, "subtree shard of an empty tree");
+        // frontier at depth `shard_depth`, left to right: nodes at that depth and leaves above it
+        std::vector<int32_t> frontier, st{t->root};
+        while (!st.empty()) {
+            int32_t v = st.back();
+            st.pop_back();
+            const Node &nd = t->nodes[v];
+            if (nd.depth == shard_depth || nd.is_leaf()) { frontier.push_back(v); continue; }
+            if (nd.right >= 0) st.push_back(nd.right);
+            if (nd.left >= 0) st.push_back(nd.left);
+        }
+        if (shard_index >= frontier.size())
+            return fail(PFQ_ERR_ARG, "subtree index " + std::to_string(shard_index) + " out of range: the depth-" +
+                                         std::to_string(shard_depth) + " frontier has " + std::to_string(frontier.size()) + " nodes");
+        const int32_t target = frontier[shard_index];
+        // leaves before the shard in the whole tree's order
+        auto count_leaves = [&](int32_t root) {
+            uint64_t n = 0;
+            std::vector<int32_t> s2{root};
+            while (!s2.empty()) {
+                int32_t v = s2.back();
+                s2.pop_back();
+                const Node &nd = t->nodes[v];
+                if (nd.is_leaf()) ++n;
+                if (nd.left >= 0) s2.push_back(nd.left);
+                if (nd.right >= 0) s2.push_back(nd.right);
+            }
+            return n;
+        };
+        for (uint64_t i = 0; i < shard_index; ++i) t->shard_first_leaf += count_leaves(frontier[i]);
+        // reduce every ancestor to the child on the path
+        for (int32_t c = target, v = t->nodes[target].parent; v >= 0; c = v, v = t->nodes[v].parent) {
+            if (t->nodes[v].left != c) t->nodes[v].left = -1;
+            if (t->nodes[v].right != c) t->nodes[v].right = -1;
+        }
+        std::fill(reachable.begin(), reachable.end(), 0);
+        std::vector<int32_t> s3{t->root};
+        while (!s3.empty()) {
+            int32_t v = s3.back();
+            s3.pop_back();
+            reachable[v] = 1;
+            if (t->nodes[v].left >= 0) s3.push_back(t->nodes[v].left);
+            if (t->nodes[v].right >= 0) s3.push_back(t->nodes[v].right);
+        }
+        t->is_shard = true;
+    }
     // filters keyed by relative path, exactly like the LRU cache key (cache.rs:56-62)
     std::map<std::string, uint32_t> row_of;
-    for (auto &nd : t->nodes) {
+    for (size_t vi = 0; vi < t->nodes.size(); ++vi) {
+        auto &nd = t->nodes[vi];
+        if (!reachable[vi]) continue;  // outside this shard: its .bf is never read
         auto it = row_of.find(nd.bf_path);
         if (it == row_of.end()) {
             nd.filter = (uint32_t)t->filter_paths.size();
@@ -748,6 +811,12 @@ int pfq_tree_open(const char *db_dir, int device, pfq_tree **out) {
     return PFQ_OK;
 }
 
+int pfq_tree_open(const char *db_dir, int device, pfq_tree **out) { return open_impl(db_dir, device, false, 0, 0, out); }
+
+int pfq_tree_open_subtree(const char *db_dir, int device, uint64_t depth, uint64_t index, pfq_tree **out) {
+    return open_impl(db_dir, device, true, depth, index, out);
+}
+
 int pfq_tree_build_balanced(const uint8_t *genomes, const uint64_t *offsets, uint64_t n_genomes, const char *const *tax_ids,
                             uint64_t kmer_size, uint64_t nbits, uint32_t num_hashes, uint64_t seed1, uint64_t seed2,
                             float false_pos_rate, uint32_t largest_expected_genome, int device, pfq_tree **out) {
@@ -785,6 +854,7 @@ int pfq_tree_save(const pfq_tree *tree, const char *db_dir) {
     if (!tree || !db_dir) return fail(PFQ_ERR_ARG, "null argument");
     PFQ_TRY(use_device(tree->device));
     const pfq_tree &t = *tree;
+    if (t.is_shard) return fail(PFQ_ERR_STATE, "a subtree shard is not a whole database and cannot be saved");
     std::string dir(db_dir);
     std::vector<uint8_t> o;
     o.push_back(t.root >= 0 ? 1 : 0);
@@ -842,6 +912,8 @@ int pfq_tree_info(const pfq_tree *tree, pfq_info *out) {
     out->n_nodes = t.nodes.size();
     out->n_leaves = leaves_dfs(t).size();
     out->n_filters = t.filter_paths.size();
+    out->shard_first_leaf = t.shard_first_leaf;
+    out->tree_leaves = t.is_shard ? t.tree_leaves : out->n_leaves;
     out->device_bytes = t.d_bits.bytes() + t.d_S.bytes() + t.d_pairs.bytes() + t.d_sorted.bytes() + t.d_fail.bytes() +
                         t.d_hit_pairs.bytes() + t.d_seq.bytes() + t.d_off.bytes() + t.d_recs.bytes();
     return PFQ_OK;

@@ -60,7 +60,6 @@ struct VerifyArgs {
     uint32_t n_sub;              // sub-queues per XCD (record kernel)
     const uint4 *recs;           // probe records written by k_classify<DEFER> (nullptr: re-hash per slice)
     uint32_t chunk;
-    uint32_t debug;              // measurement switches (PFQ_VERIFY_DEBUG): 1 = probe leaf 0 only, 2 = no probe loads
 };
 
 struct FinalizeArgs {

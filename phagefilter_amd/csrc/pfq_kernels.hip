@@ -45,12 +45,10 @@ __device__ __forceinline__ bool verify_column(BlockLds &lds, uint32_t wave, cons
         ProbeIter it;
         it.init(h1, h2, a.hp);
         uint32_t ok = 1;
-#pragma unroll 5
-        for (uint32_t i = 0; i < a.hp.num_hashes; ++i) {
-            uint32_t idx = it.get(i, a.hp);
+        for_each_probe(it, a.hp, [&](uint32_t idx) {
             uint32_t v = valid ? a.S[(uint64_t)idx * a.rw + cw] : 0u;
             ok &= (v >> cb);
-        }
+        });
         uint64_t b = ballot64(valid && (ok & 1u));
         hits += (uint64_t)__popcll(b);
         seen += cnt;
@@ -359,7 +357,7 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs a) {
                 const uint64_t o0 = a.off[p.x], L = a.off[p.x + 1] - o0;
                 const uint64_t n = L - a.hp.k + 1;  // candidates always have n >= 1
                 const uint8_t *read = a.seq + o0;
-                const uint32_t *bm = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)a.col_row[(a.debug & 1u) ? 0u : p.y] * a.n_words);
+                const uint32_t *bm = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)a.col_row[p.y] * a.n_words);
                 bool miss = false;
                 for (uint64_t base = 0; base < n; base += WIN_KMERS) {
                     uint32_t cnt = (uint32_t)((n - base) < WIN_KMERS ? (n - base) : WIN_KMERS);
@@ -370,13 +368,11 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs a) {
                     ProbeIter pit;
                     pit.init(h1, h2, a.hp);
                     uint32_t ok = 1;
-#pragma unroll 5
-                    for (uint32_t i = 0; i < a.hp.num_hashes; ++i) {
-                        uint32_t idx = pit.get(i, a.hp);
-                        bool in = valid && (idx - lo) < a.slice_bits && !(a.debug & 2u);
+                    for_each_probe(pit, a.hp, [&](uint32_t idx) {
+                        bool in = valid && (idx - lo) < a.slice_bits;
                         uint32_t v = in ? bm[idx >> 5] : ~0u;
-                        ok &= (v >> (idx & 31u)) | (a.debug & 1u) | (idx & a.debug & 4u);
-                    }
+                        ok &= v >> (idx & 31u);
+                    });
                     miss = !(ok & 1u);
                     if (ballot64(miss)) { miss = true; break; }
                 }
@@ -402,7 +398,7 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
     const uint32_t per_wave = a.chunk < 64u ? a.chunk : 64u, item_pairs = per_wave * (blockDim.x >> 6);
     const uint64_t n_items = (n_pairs + item_pairs - 1) / item_pairs;
     const uint32_t home = xcc_id() & 7u, groups = 8u / a.n_slices;
-    const uint32_t d = (uint32_t)a.hp.nbits, dw = d - (uint32_t)a.hp.w64, k = a.hp.k;
+    const uint32_t d = (uint32_t)a.hp.nbits, dw = d - (uint32_t)a.hp.w64, k = a.hp.k, nh = a.hp.num_hashes;
 
     auto load_meta = [&](uint64_t it) -> uint4 {
         const uint64_t e = it * item_pairs + (uint64_t)wave * per_wave + lane;
@@ -439,7 +435,7 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
                 const uint64_t o0 = ((uint64_t)bcast_u32(meta_cur.y, j) << 32) | bcast_u32(meta_cur.x, j);
                 const uint64_t n = (uint64_t)bcast_u32(meta_cur.z, j) - k + 1;  // candidates always have n >= 1
                 const uint4 *rp = a.recs + o0;
-                const uint32_t row = (a.debug & 1u) ? 0u : bcast_u32(meta_cur.w, j);
+                const uint32_t row = bcast_u32(meta_cur.w, j);
                 const uint32_t *bm = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)row * a.n_words);
                 bool miss = false;
                 for (uint64_t g0 = 0; g0 < n; g0 += 3 * WIN_KMERS) {
@@ -449,20 +445,44 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
                     for (int w = 0; w < 3; ++w) {
                         const uint64_t qq = g0 + 64u * w + lane;
                         valid[w] = qq < n;
-                        rec[w] = (valid[w] && !(a.debug & 8u)) ? rp[qq] : make_uint4(lane, (uint32_t)qq, 7u, 0u);
+                        rec[w] = valid[w] ? rp[qq] : make_uint4(0, 0, 0, 0);
                     }
+                    // probes 0..2 of the three windows: nine independent gathers, then the walk two probes at a
+                    // time per window (six gathers in flight); uses come after the loads of a batch
+                    RecordIter rit[3];
                     uint32_t ok = 1;
+                    {
+                        uint32_t ix[9], vv[9];
 #pragma unroll
-                    for (int w = 0; w < 3; ++w) {
-                        RecordIter rit;
-                        rit.init(rec[w]);
-#pragma unroll 5
-                        for (uint32_t i = 0; i < a.hp.num_hashes; ++i) {
-                            const uint32_t idx = rit.get(i, d, dw);
-                            const bool in = valid[w] && (idx - lo) < a.slice_bits && !(a.debug & 2u);
-                            const uint32_t v = in ? bm[idx >> 5] : ~0u;
-                            ok &= (v >> (idx & 31u)) | (a.debug & 1u);
+                        for (int w = 0; w < 3; ++w) {
+                            rit[w].init(rec[w]);
+                            ix[3 * w] = rit[w].i0;
+                            ix[3 * w + 1] = rit[w].g;
+                            ix[3 * w + 2] = rit[w].x;
                         }
+#pragma unroll
+                        for (int u = 0; u < 9; ++u) {
+                            const bool in = valid[u / 3] && (u % 3) < (int)nh && (ix[u] - lo) < a.slice_bits;
+                            vv[u] = in ? bm[ix[u] >> 5] : ~0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 9; ++u) ok &= vv[u] >> (ix[u] & 31u);
+                    }
+                    for (uint32_t i = 3; i < nh; i += 2) {
+                        const bool second = i + 1 < nh;  // wave-uniform
+                        uint32_t ix[6], vv[6];
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) {
+                            ix[2 * w] = rit[w].step(d, dw);
+                            ix[2 * w + 1] = second ? rit[w].step(d, dw) : 0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 6; ++u) {
+                            const bool in = valid[u / 2] && ((u & 1) == 0 || second) && (ix[u] - lo) < a.slice_bits;
+                            vv[u] = in ? bm[ix[u] >> 5] : ~0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 6; ++u) ok &= vv[u] >> (ix[u] & 31u);
                     }
                     miss = miss || !(ok & 1u);
                 }
@@ -543,10 +563,9 @@ __global__ void __launch_bounds__(256) k_insert(HashParams hp, const uint8_t *ge
         kmer_hashes(lds, wave, lane, cnt, valid, hp, h1, h2);
         ProbeIter it;
         it.init(h1, h2, hp);
-        for (uint32_t i = 0; i < hp.num_hashes; ++i) {
-            uint32_t idx = it.get(i, hp);
+        for_each_probe(it, hp, [&](uint32_t idx) {
             if (valid) atomicOr(&row[idx >> 6], 1ull << (idx & 63u));
-        }
+        });
     }
 }
 void launch_insert(const HashParams &hp, const uint8_t *d_genomes, const uint64_t *d_goff, uint32_t n_genomes,
@@ -640,10 +659,11 @@ __global__ void __launch_bounds__(256) k_debug_indices(HashParams hp, const uint
         kmer_hashes(lds, wave, lane, cnt, valid, hp, h1, h2);
         ProbeIter it;
         it.init(h1, h2, hp);
-        for (uint32_t i = 0; i < hp.num_hashes; ++i) {
-            uint32_t idx = it.get(i, hp);
+        uint32_t i = 0;
+        for_each_probe(it, hp, [&](uint32_t idx) {
             if (valid) out[(base + lane) * hp.num_hashes + i] = idx;
-        }
+            ++i;
+        });
     }
 }
 void launch_debug_indices(const HashParams &hp, const uint8_t *d_seq, uint64_t len, uint64_t *d_out, hipStream_t st) {

@@ -38,3 +38,21 @@ def reduce_tree_counts(tree, device=None, stream: int = 0):
     tree.import_counts(buf.data_ptr(), stream)
     torch.cuda.current_stream().synchronize()
     return buf
+
+
+def gather_shard_counts(tree, device=None, stream: int = 0):
+    """Subtree-sharded trees (BloomTree.load_subtree, one shard per rank, every rank classifies all reads): the
+    shards' leaf ranges are disjoint, so the whole tree's counters are one all-reduce of a zero-padded vector in
+    which each rank fills its own range [shard_first_leaf, shard_first_leaf + n_leaves)."""
+    import torch
+    info = tree.info()
+    n, first, total = int(info.n_leaves), int(info.shard_first_leaf), int(info.tree_leaves)
+    dev = device if device is not None else f"cuda:{tree.device}"
+    full = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+    if n:
+        local = torch.zeros(n, dtype=torch.int64, device=dev)
+        tree.export_counts(local.data_ptr(), stream)
+        torch.cuda.current_stream().synchronize()
+        full[first:first + n] = local
+    all_reduce_counts(full)
+    return full

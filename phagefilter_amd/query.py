@@ -56,6 +56,14 @@ class BloomTree:
         return cls(h, device)
 
     @classmethod
+    def load_subtree(cls, directory: str, depth: int, index: int, device: int = 0) -> "BloomTree":
+        """Shard `index` of the depth-`depth` frontier (pfq_tree_open_subtree): that node, its subtree and its
+        ancestor chain.  For trees that do not fit one GPU: one shard per rank, every rank sees all reads."""
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().pfq_tree_open_subtree(directory.encode(), device, depth, index, C.byref(h)))
+        return cls(h, device)
+
+    @classmethod
     def build_balanced(cls, genomes: Sequence[bytes], tax_ids: Sequence[str], kmer_size: int, nbits: int,
                        num_hashes: int, seed1: int, seed2: int, false_pos_rate: float = 0.001,
                        largest_expected_genome: int = 1000000, device: int = 0) -> "BloomTree":

@@ -400,3 +400,44 @@ def test_config3_properties_1024_leaves(gpu):
     assert np.array_equal(sum(counts(0, a, b) for a, b in zip(thirds, thirds[1:])), whole)  # path/block independent
     assert np.array_equal(counts(1, 0, n_reads), whole)                                  # idempotent
     gt.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# subtree shards (BASELINE config 5: a tree larger than one GPU, one shard per rank, every rank sees all reads)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("depth,corrupt_root", [(0, False), (1, False), (2, False), (3, True), (3, False), (6, False)])
+def test_subtree_shards_concatenate_to_whole_tree(gpu, tmp_path, depth, corrupt_root):
+    genomes = [rand_dna(int(RNG.integers(400, 900))) for _ in range(13)]
+    genomes[5] = genomes[4]                                        # a read hitting leaves of two different shards
+    ot, ids = oracle_tree(genomes, 21, 50021, 7)
+    if corrupt_root:                                               # ancestors outside the shard must still be honoured
+        ot.bits[ot.filter_of[ot.root]][::3] = 0
+    d = str(tmp_path / "db")
+    fmt.write_db(ot, d)
+    reads = make_reads(genomes, 150, 40, 120, 21, errors=False)
+    seq, off = pack_reads(reads)
+    for thr in (1.0, 0.5):
+        for v in range(ot.n_nodes):
+            ot.mapped_reads[v] = 0
+        ohits, _, _ = orc.query_batch(ot, reads, thr)
+        want_counts, want_hits = ot.leaf_counts(), oracle_hits(ot, ohits)
+        got_counts, got_hits, next_leaf, i = [], [], 0, 0
+        while True:
+            try:
+                sh = BloomTree.load_subtree(d, depth, i)
+            except PfqError as e:
+                assert e.code == -1 and i > 0
+                break
+            info = sh.info()
+            assert info.shard_first_leaf == next_leaf and info.tree_leaves == len(want_counts)
+            offs, leaves = sh.query_packed(seq, off, thr, want_hits=True)
+            got_counts += sh.get_leaf_counts()
+            got_hits += [(r, c + next_leaf) for r, c in hits_of(offs, leaves)]
+            next_leaf += int(info.n_leaves)
+            with pytest.raises(PfqError):
+                sh.save(str(tmp_path / "nope"))
+            sh.close()
+            i += 1
+        assert next_leaf == len(want_counts)
+        assert got_counts == want_counts, (depth, thr)
+        assert sorted(got_hits) == want_hits, (depth, thr)
