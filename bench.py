@@ -81,9 +81,13 @@ def main() -> None:
     # ---- reads: every (step, rank) gets its own slice of the global read index space, resident in HBM
     n_batches = min(args.steps + args.warmup, 16)
     reads = torch.empty(n_batches * B * rl + 64, dtype=torch.uint8, device=dev)
+    src_genomes = genomes
+    if os.environ.get("PFQ_BENCH_ALL_NEGATIVE") == "1":  # experiment: reads drawn from genomes that are NOT in the tree
+        src_genomes = torch.empty(n_g * glen, dtype=torch.uint8, device=dev)
+        _ffi.check(L.pfq_synth_genomes_device(src_genomes.data_ptr(), n_g, glen, GENOME_SEED + 0x100000, None))
     for b in range(n_batches):
         first = (b * world + rank) * B
-        _ffi.check(L.pfq_synth_reads_device(reads.data_ptr() + b * B * rl, first, B, rl, genomes.data_ptr(), glen, n_g,
+        _ffi.check(L.pfq_synth_reads_device(reads.data_ptr() + b * B * rl, first, B, rl, src_genomes.data_ptr(), glen, n_g,
                                             READ_SEED, None))
     off = torch.arange(B + 1, dtype=torch.int64, device=dev) * rl
     torch.cuda.synchronize()

@@ -142,11 +142,11 @@ __device__ __forceinline__ uint64_t rotl64(uint64_t x, uint32_t r) { return (x <
 
 // The two seeded hashes of the canonical k-mer at window position q (per lane).
 // Canonical choice (file_parser.rs:116-120): forward unless revcomp is bytewise smaller.
-__device__ __forceinline__ void kmer_hashes(const BlockLds &lds, uint32_t wave, uint32_t q, uint32_t cnt, bool valid,
-                                            const HashParams &hp, uint64_t &h1, uint64_t &h2) {
-    const uint32_t *fw = lds.win[wave][0], *rw = lds.win[wave][1];
-    uint32_t k = hp.k, W = cnt + k - 1;
-    uint32_t fa = WIN_PAD + q, ra = WIN_PAD + (W - q - k);
+// fw / rw: LDS word arrays holding forward and reverse-complement bytes; fa / ra: per-lane byte addresses of the
+// forward k-mer and of its reverse complement inside them.
+__device__ __forceinline__ void kmer_hashes_at(const uint32_t *fw, const uint32_t *rw, uint32_t fa, uint32_t ra, bool valid,
+                                               const HashParams &hp, uint64_t &h1, uint64_t &h2) {
+    const uint32_t k = hp.k;
     if (!valid) { fa = WIN_PAD; ra = WIN_PAD; }
     // bytewise lexicographic compare == compare of byte-swapped dwords, first difference decides
     bool use_rc = false, decided = !valid;
@@ -166,6 +166,24 @@ __device__ __forceinline__ void kmer_hashes(const BlockLds &lds, uint32_t wave, 
     h1 = rotl64((hp.a1 + hb) * FX_K, 26);
     h2 = rotl64((hp.a2 + hb) * FX_K, 26);
 }
+// k-mer at position q of the window staged by stage_window(…, cnt, …)
+__device__ __forceinline__ void kmer_hashes(const BlockLds &lds, uint32_t wave, uint32_t q, uint32_t cnt, bool valid,
+                                            const HashParams &hp, uint64_t &h1, uint64_t &h2) {
+    const uint32_t W = cnt + hp.k - 1;
+    kmer_hashes_at(lds.win[wave][0], lds.win[wave][1], WIN_PAD + q, WIN_PAD + (W - q - hp.k), valid, hp, h1, h2);
+}
+
+// ---- dense pre-screen staging: the first DENSE_KMERS k-mers of DENSE_READS reads per wave ------------------------------
+constexpr uint32_t DENSE_READS = 16, DENSE_KMERS = 4;               // 16 x 4 = 64 lanes
+constexpr uint32_t MINI_BYTES = 84;                                  // >= WIN_PAD + (KMAX + DENSE_KMERS - 1) + WIN_PAD, dword multiple
+template <bool ENABLED>
+struct DenseLds {
+    uint32_t mini[WAVES_PER_BLOCK][2][DENSE_READS * MINI_BYTES / 4];
+};
+template <>
+struct DenseLds<false> {
+    uint32_t mini[1][2][1];
+};
 
 // ---- exact `% nbits` ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mod_nbits(uint64_t r, const HashParams &hp) {

@@ -147,10 +147,114 @@ __device__ __forceinline__ uint32_t screen_counts(BlockLds &lds, uint32_t wave, 
     return live;
 }
 
+// ---- dense pre-screen (theta == 1) -------------------------------------------------------------------------------------
+// Most reads of a metagenome hit nothing, and the AND-frontier needs only their first four k-mers: a wave screens
+// DENSE_READS reads per pass with lane = (read, k-mer), so one hashing pass serves 16 reads instead of one.
+// Returns the mask of reads that must go through the per-read path: frontier not empty, or not a regular read
+// (no k-mers, need != n).  Reads outside the mask are finished: no leaf can pass them.
+__device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, const uint8_t *comp, const QueryArgs &a,
+                                                 uint64_t r0, uint32_t n_in_group, uint32_t colmask, uint64_t &lane_len) {
+    const uint32_t lane = lane_id(), j = lane >> 2, t = lane & 3u, k = a.hp.k;
+    const uint32_t rw = a.rw, slots = 64u >> a.rw_log2, word = lane & (rw - 1u), slot = lane >> a.rw_log2;
+    uint64_t o0 = 0, L = 0;
+    if (j < n_in_group) {
+        o0 = a.off[r0 + j];
+        L = a.off[r0 + j + 1] - o0;
+    }
+    lane_len = (t == 0) ? L : 0;  // read length, on the first lane of each read
+    const uint64_t n = (L >= k) ? (L - k + 1) : 0;
+    const bool regular = j < n_in_group && n >= 1 && need_kmers(a.threshold, n) == n;
+    const uint32_t nk = regular ? (uint32_t)(n < DENSE_KMERS ? n : DENSE_KMERS) : 0u;
+    const uint32_t W = nk ? nk + k - 1 : 0u;  // bytes of this read that are staged
+    uint8_t *fwd = reinterpret_cast<uint8_t *>(fw), *rcb = reinterpret_cast<uint8_t *>(rw_);
+    const uint32_t mb = j * MINI_BYTES + WIN_PAD;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i0 = 0; i0 < k + DENSE_KMERS - 1; i0 += 24) {  // six bytes per lane and batch, loads before uses
+        uint8_t b[6];
+#pragma unroll
+        for (uint32_t u = 0; u < 6; ++u) {
+            const uint32_t idx = i0 + 4u * u + t;
+            b[u] = idx < W ? a.seq[o0 + idx] : (uint8_t)0;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 6; ++u) {
+            const uint32_t idx = i0 + 4u * u + t;
+            if (idx < W) {
+                fwd[mb + idx] = b[u];
+                rcb[mb + (W - 1 - idx)] = comp[b[u]];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool valid = t < nk;
+    uint64_t h1, h2;
+    kmer_hashes_at(fw, rw_, mb + t, mb + (W - t - k), valid, a.hp, h1, h2);
+    const uint32_t i0v = mod_nbits(h1, a.hp), i1v = mod_nbits(h2, a.hp);
+    const bool two = a.hp.num_hashes > 1;
+    uint32_t survive = 0;
+    // Row gathers, 16 bytes per lane: a read's 2*nk rows of rw dwords are covered by lanes (row = lane / (rw/4),
+    // part = lane % (rw/4)); with rw = 32 one load instruction fetches all 8 rows of a read.  The loads of
+    // DENSE_BATCH reads are issued before any is consumed.  (rw >= 4 here; smaller trees skip the pre-screen.)
+    const uint32_t lpr = rw >> 2, lpr_log2 = a.rw_log2 - 2u;       // lanes per row
+    const uint32_t rpi = 64u >> lpr_log2;                           // rows per load instruction
+    const uint32_t part = lane & (lpr - 1u), rsel = lane >> lpr_log2;
+    // leaf-column mask of my four dwords
+    uint32_t cm[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t w = part * 4u + u;
+        cm[u] = (w * 32u < a.n_leaves) ? ((a.n_leaves - w * 32u >= 32u) ? ~0u : ((1u << (a.n_leaves - w * 32u)) - 1u)) : 0u;
+    }
+    constexpr uint32_t DENSE_BATCH = 8;
+    for (uint32_t jb = 0; jb < n_in_group; jb += DENSE_BATCH) {
+        uint4 acc[DENSE_BATCH];
+#pragma unroll
+        for (uint32_t u = 0; u < DENSE_BATCH; ++u) {
+            const uint32_t jj = jb + u;
+            acc[u] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            if (jj >= n_in_group) continue;
+            const uint32_t nk_j = bcast_u32(nk, (int)((jj < DENSE_READS ? jj : 0u) * 4u));
+            const uint32_t rows = 2u * nk_j;
+            for (uint32_t p0 = 0; p0 < rows; p0 += rpi) {
+                const uint32_t p = p0 + rsel;
+                const bool pv = p < rows && ((p & 1u) == 0 || two);
+                const int src = (int)(jj * 4u + ((pv ? p : 0u) >> 1));
+                const uint32_t x0 = (uint32_t)__shfl((int)i0v, src), x1 = (uint32_t)__shfl((int)i1v, src);
+                const uint32_t idx = (p & 1u) ? x1 : x0;
+                if (pv) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(a.S + (uint64_t)idx * rw + part * 4u);
+                    acc[u].x &= v.x; acc[u].y &= v.y; acc[u].z &= v.z; acc[u].w &= v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < DENSE_BATCH; ++u) {
+            const uint32_t jj = jb + u;
+            if (jj >= n_in_group) continue;
+            const uint32_t nk_j = bcast_u32(nk, (int)(jj * 4u));
+            if (nk_j == 0) {  // irregular read: leave it to the per-read path
+                survive |= 1u << jj;
+                continue;
+            }
+            uint4 l4 = acc[u];
+            for (uint32_t sft = lpr; sft < 64u; sft <<= 1) {  // AND over the rows held by other lanes
+                l4.x &= (uint32_t)__shfl_xor((int)l4.x, (int)sft);
+                l4.y &= (uint32_t)__shfl_xor((int)l4.y, (int)sft);
+                l4.z &= (uint32_t)__shfl_xor((int)l4.z, (int)sft);
+                l4.w &= (uint32_t)__shfl_xor((int)l4.w, (int)sft);
+            }
+            const bool any = ((l4.x & cm[0]) | (l4.y & cm[1]) | (l4.z & cm[2]) | (l4.w & cm[3])) != 0;
+            if (ballot64(any)) survive |= 1u << jj;
+        }
+    }
+    return survive;
+}
+
 // ---- the classification kernel ---------------------------------------------------------------------------------------
 template <bool DEFER, bool COUNTS>
 __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
     __shared__ BlockLds lds;
+    __shared__ DenseLds<DEFER && !COUNTS> dlds;
     fill_complement(lds.comp);
     __syncthreads();
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -160,12 +264,13 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
     uint32_t colmask = 0;  // leaf columns of my dword
     if (word * 32u < a.n_leaves) colmask = (a.n_leaves - word * 32u >= 32u) ? ~0u : ((1u << (a.n_leaves - word * 32u)) - 1u);
     unsigned long long st_cand = 0, st_hits = 0, st_all = 0, st_bytes = 0, st_def = 0;
+    unsigned long long dense_bytes = 0;  // per lane
     // deferred pairs are appended through per-wave reservations of PAIR_CHUNK slots: one atomic on the shared
     // cursor per chunk (a single hot address saturates at ~88 atomics/us); unused slots are voided at the end
     unsigned long long pair_base = 0;
     uint32_t pair_used = PAIR_CHUNK;
 
-    for (uint64_t r = gw; r < a.n_reads; r += nw) {
+    auto process_read = [&](uint64_t r) {
         const uint64_t o0 = a.off[r], L = a.off[r + 1] - o0;
         ReadCtx rc;
         rc.read = a.seq + o0;
@@ -175,9 +280,9 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
         if (rc.need == 0) {  // 0 >= 0 at every node: the read reaches and counts at every leaf
             ++st_all;
             if (a.allhit_flag && lane == 0) a.allhit_flag[r] = 1;
-            continue;
+            return;
         }
-        if (rc.need > rc.n) continue;  // cannot pass any node
+        if (rc.need > rc.n) return;  // cannot pass any node
         rc.maxmiss = rc.n - rc.need;
 
         // The AND-frontier is only valid when no miss is tolerated; (n as f32) rounds for n >= 2^24, so even at
@@ -249,12 +354,33 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
                 }
             }
         }
+    };
+
+    if (DEFER && !COUNTS && a.rw >= 4u) {
+        // groups of DENSE_READS consecutive reads: dense pre-screen, then the per-read path for the survivors
+        const uint64_t n_groups = (a.n_reads + DENSE_READS - 1) / DENSE_READS;
+        for (uint64_t g = gw; g < n_groups; g += nw) {
+            const uint64_t r0 = g * DENSE_READS;
+            const uint32_t cnt = (uint32_t)(a.n_reads - r0 < DENSE_READS ? a.n_reads - r0 : DENSE_READS);
+            uint64_t lane_len;
+            uint32_t survive = dense_screen(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, a, r0, cnt, colmask, lane_len);
+            if (!((survive >> (lane >> 2)) & 1u)) dense_bytes += lane_len;  // reads finished here still count their bytes
+            while (survive) {
+                const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
+                survive &= survive - 1u;
+                process_read(r0 + jj);
+            }
+        }
+    } else {
+        for (uint64_t r = gw; r < a.n_reads; r += nw) process_read(r);
     }
     if (DEFER && pair_used < PAIR_CHUNK)
         for (uint32_t i = pair_used + lane; i < PAIR_CHUNK; i += 64) a.pairs[pair_base + i] = make_uint2(0xffffffffu, 0xffffffffu);
     // reads that pass every node (need == 0) count at every leaf (query.rs:143 reached through every path)
     if (st_all)
         for (uint32_t c = lane; c < a.n_leaves; c += 64) atomicAdd(&a.counts[c], st_all);
+    for (int dd = 32; dd > 0; dd >>= 1) dense_bytes += __shfl_down(dense_bytes, dd);
+    st_bytes += bcast_u32((uint32_t)dense_bytes, 0) | ((unsigned long long)bcast_u32((uint32_t)(dense_bytes >> 32), 0) << 32);
     if (lane == 0) {
         if (st_cand) atomicAdd(&a.stats[ST_CANDIDATES], st_cand);
         if (st_hits) atomicAdd(&a.stats[ST_HITS], st_hits);
