@@ -17,8 +17,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <set>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -103,13 +106,15 @@ Fmt detect_format(const std::string &path, FmtOverride ov) {  // file_parser.rs:
     return format_from_extension(path);
 }
 
-// Line reader over a (possibly gzip-compressed) file.
+// Line reader over a (possibly gzip-compressed) file.  Lines are handed out as views into the read buffer
+// (no per-line allocation); a line that straddles a buffer refill is assembled in `carry`.
 struct LineReader {
     gzFile f = nullptr;
     std::vector<char> buf;
+    std::string carry;
     size_t pos = 0, len = 0;
     bool eof = false;
-    explicit LineReader(const std::string &path) : buf(1 << 20) {
+    explicit LineReader(const std::string &path) : buf(4 << 20) {
         f = gzopen(path.c_str(), "rb");
         if (!f) die("Failed to open '" + path + "': " + strerror(errno));
         gzbuffer(f, 1 << 20);
@@ -117,102 +122,138 @@ struct LineReader {
     ~LineReader() {
         if (f) gzclose(f);
     }
-    // Reads one line without its '\n' into `out`; false at end of file with nothing read.
-    bool next(std::string &out) {
-        out.clear();
-        bool any = false;
+    // One line without its '\n' as [p, p+n); false at end of file with nothing read.  The view stays valid until
+    // the next call.
+    bool next(const char *&p, size_t &n) {
+        bool use_carry = false;
         while (true) {
             if (pos == len) {
-                if (eof) return any;
-                int n = gzread(f, buf.data(), (unsigned)buf.size());
-                if (n < 0) die("read error (corrupt gzip?)");
-                if (n == 0) {
-                    eof = true;
-                    return any;
+                if (eof) {
+                    if (use_carry) { p = carry.data(); n = carry.size(); return true; }
+                    return false;
                 }
+                int got = gzread(f, buf.data(), (unsigned)buf.size());
+                if (got < 0) die("read error (corrupt gzip?)");
+                if (got == 0) { eof = true; continue; }
                 pos = 0;
-                len = (size_t)n;
+                len = (size_t)got;
             }
-            const char *p = buf.data() + pos;
-            const char *nl = (const char *)memchr(p, '\n', len - pos);
+            const char *b = buf.data() + pos;
+            const char *nl = (const char *)memchr(b, '\n', len - pos);
             if (nl) {
-                out.append(p, nl - p);
-                pos += (size_t)(nl - p) + 1;
+                if (use_carry) {
+                    carry.append(b, nl - b);
+                    p = carry.data();
+                    n = carry.size();
+                } else {
+                    p = b;
+                    n = (size_t)(nl - b);
+                }
+                pos += (size_t)(nl - b) + 1;
                 return true;
             }
-            out.append(p, len - pos);
+            if (!use_carry) { carry.clear(); use_carry = true; }
+            carry.append(b, len - pos);
             pos = len;
-            any = true;
         }
     }
 };
 
-void trim_end(std::string &s) {  // str::trim_end
-    while (!s.empty() && isspace((unsigned char)s.back())) s.pop_back();
+inline size_t trimmed_len(const char *p, size_t n) {  // str::trim_end
+    while (n && isspace((unsigned char)p[n - 1])) --n;
+    return n;
 }
-std::string id_of(const std::string &header) {  // bio Record::id(): first whitespace-delimited token after the marker
-    std::string h = header.substr(1);
-    trim_end(h);
-    size_t i = 0;
-    while (i < h.size() && !isspace((unsigned char)h[i])) ++i;
-    return h.substr(0, i);
+std::string id_of(const char *h, size_t n) {  // bio Record::id(): first whitespace-delimited token after the marker
+    n = trimmed_len(h, n);
+    size_t i = 1;
+    while (i < n && !isspace((unsigned char)h[i])) ++i;
+    return std::string(h + 1, i > 1 ? i - 1 : 0);
 }
 
-struct Record {
-    std::string id, seq, qual;
-    bool has_qual = false;
+// One block of reads in the layout the C ABI takes (concatenated bases + n+1 offsets); ids and qualities are kept
+// only when POS/NEG filtering needs them (the reference drops them otherwise too, file_parser.rs:202-204,217-220).
+struct Batch {
+    std::vector<uint8_t> seq;
+    std::vector<uint64_t> off{0};
+    std::vector<std::string> ids;
+    std::vector<char> qual;           // concatenated qualities (same offsets as seq) when has_qual
+    std::vector<uint8_t> has_qual;    // per read
+    size_t n() const { return off.size() - 1; }
+    void clear() {
+        seq.clear();
+        off.assign(1, 0);
+        ids.clear();
+        qual.clear();
+        has_qual.clear();
+    }
 };
 
-// bio::io::fasta / fastq record iteration (multi-line sequences; FASTQ qualities read until they cover the sequence)
+// bio::io::fasta / fastq record iteration (multi-line sequences; FASTQ qualities read until they cover the
+// sequence), appending straight into a Batch.
 struct RecordReader {
     LineReader lr;
     Fmt fmt;
-    std::string line;
-    bool have_line = false, started = false;
+    std::string pending;  // a header line already consumed while finishing the previous FASTA record
+    bool have_pending = false;
     RecordReader(const std::string &path, Fmt f) : lr(path), fmt(f) {}
-    bool next(Record &r) {
-        if (!have_line) {
-            if (!lr.next(line)) return false;
-            have_line = true;
+    bool next(Batch &b, bool keep) {
+        const char *p;
+        size_t n;
+        std::string header;
+        if (have_pending) {
+            header.swap(pending);
+            have_pending = false;
+        } else {
+            if (!lr.next(p, n)) return false;
+            if (n == 0 && lr.eof && lr.pos == lr.len) return false;
+            header.assign(p, n);
         }
-        if (line.empty() && lr.eof) return false;
-        r.seq.clear();
-        r.qual.clear();
+        const size_t seq0 = b.seq.size();
         if (fmt == Fmt::Fasta) {
-            if (line.empty() || line[0] != '>') die("FASTA: Expected > at record start.");
-            r.id = id_of(line);
-            r.has_qual = false;
-            have_line = false;
-            while (lr.next(line)) {
-                if (!line.empty() && line[0] == '>') {
-                    have_line = true;
+            if (header.empty() || header[0] != '>') die("FASTA: Expected > at record start.");
+            while (lr.next(p, n)) {
+                if (n && p[0] == '>') {
+                    pending.assign(p, n);
+                    have_pending = true;
                     break;
                 }
-                trim_end(line);
-                r.seq += line;
+                n = trimmed_len(p, n);
+                b.seq.insert(b.seq.end(), p, p + n);
+            }
+            b.off.push_back(b.seq.size());
+            if (keep) {
+                b.ids.push_back(id_of(header.data(), header.size()));
+                b.has_qual.push_back(0);
+                b.qual.resize(b.seq.size(), 0);
             }
             return true;
         }
-        if (line.empty() || line[0] != '@') die("FASTQ: Expected @ at record start.");
-        r.id = id_of(line);
-        r.has_qual = true;
-        have_line = false;
+        if (header.empty() || header[0] != '@') die("FASTQ: Expected @ at record start.");
         bool plus = false;
-        while (lr.next(line)) {
-            if (!line.empty() && line[0] == '+') {
+        while (lr.next(p, n)) {
+            if (n && p[0] == '+') {
                 plus = true;
                 break;
             }
-            trim_end(line);
-            r.seq += line;
+            n = trimmed_len(p, n);
+            b.seq.insert(b.seq.end(), p, p + n);
         }
         if (!plus) die("FASTQ: Incomplete record (missing '+' line).");
-        while (r.qual.size() < r.seq.size()) {
-            if (!lr.next(line)) die("FASTQ: Incomplete record (quality shorter than sequence).");
-            trim_end(line);
-            r.qual += line;
+        const size_t slen = b.seq.size() - seq0;
+        size_t qlen = 0;
+        if (keep) b.qual.resize(seq0, 0);
+        while (qlen < slen) {
+            if (!lr.next(p, n)) die("FASTQ: Incomplete record (quality shorter than sequence).");
+            n = trimmed_len(p, n);
+            if (keep) b.qual.insert(b.qual.end(), p, p + n);
+            qlen += n;
         }
-        if (r.qual.size() != r.seq.size()) die("FASTQ: Unequal length of sequence and quality.");
+        if (qlen != slen) die("FASTQ: Unequal length of sequence and quality.");
+        b.off.push_back(b.seq.size());
+        if (keep) {
+            b.ids.push_back(id_of(header.data(), header.size()));
+            b.has_qual.push_back(1);
+        }
         return true;
     }
 };
@@ -225,7 +266,7 @@ struct ReadQueue {
     ReadQueue(const std::string &path, FmtOverride o) : files(get_file_names(path)), ov(o) {}
     ~ReadQueue() { delete cur; }
     Fmt peek_format() const { return files.empty() ? Fmt::Fasta : detect_format(files.back(), ov); }
-    bool next(Record &r) {
+    bool next(Batch &b, bool keep) {
         while (true) {
             if (!cur) {
                 if (files.empty()) return false;
@@ -233,10 +274,16 @@ struct ReadQueue {
                 files.pop_back();
                 cur = new RecordReader(p, detect_format(p, ov));
             }
-            if (cur->next(r)) return true;
+            if (cur->next(b, keep)) return true;
             delete cur;
             cur = nullptr;
         }
+    }
+    // Appends up to max_reads reads (and at most ~max_bytes bases); false when the input is exhausted.
+    bool fill(Batch &b, uint64_t max_reads, uint64_t max_bytes, bool keep) {
+        while (b.n() < max_reads && b.seq.size() < max_bytes)
+            if (!next(b, keep)) return false;
+        return true;
     }
 };
 
@@ -404,58 +451,88 @@ int cmd_query(int argc, char **argv) {
     // The device processes big batches; ResultMap semantics (ids merged per reference block, cleared per block,
     // main.rs:334-368) are applied per `block` consecutive reads so the outputs do not depend on the batch size.
     if (block == 0) block = 1;  // the reference would loop forever on empty blocks; treat 0 as 1
-    const uint64_t batch_reads = std::max<uint64_t>(block, 1u << 20) / block * block;
-    std::vector<uint8_t> seq;
-    std::vector<uint64_t> off;
-    std::vector<Record> recs;  // kept only when filtering (ids / qualities / sequences)
-    Record r;
-    bool more = true;
-    while (more) {
-        seq.clear();
-        off.assign(1, 0);
-        recs.clear();
-        while (off.size() - 1 < batch_reads && seq.size() < (3ull << 30)) {
-            if (!rq.next(r)) {
-                more = false;
-                break;
+    const uint64_t batch_reads = std::max<uint64_t>(block, 4u << 20) / block * block;
+    // Parsing runs on its own thread, one block ahead of the GPU (double buffering).
+    Batch batches[2];
+    std::mutex mu;
+    std::condition_variable cv;
+    int ready[2] = {0, 0};   // 0 = free for the parser, 1 = filled, 2 = filled and last
+    std::thread parser([&] {
+        bool more = true;
+        for (int i = 0; more; i ^= 1) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return ready[i] == 0; });
             }
-            seq.insert(seq.end(), r.seq.begin(), r.seq.end());
-            off.push_back(seq.size());
-            if (filtering) recs.push_back(r);
+            batches[i].clear();
+            more = rq.fill(batches[i], batch_reads, 3ull << 30, filtering);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ready[i] = more ? 1 : 2;
+            }
+            cv.notify_all();
         }
-        const uint64_t n = off.size() - 1;
-        if (n == 0) break;
-        seq.resize(seq.size() + 16);
-        pfq_hits hits{};
-        check(pfq_query_batch(tree, seq.data(), off.data(), n, threshold, filtering ? PFQ_WANT_HITS : 0, filtering ? &hits : nullptr));
-        if (!filtering) continue;
-        for (uint64_t b0 = 0; b0 < n; b0 += block) {
-            const uint64_t b1 = std::min(n, b0 + block);
-            std::map<std::string, std::set<uint32_t>> result_map;  // read id -> leaf set (result_map.rs:20-22)
-            for (uint64_t i = b0; i < b1; ++i)
-                for (uint64_t j = hits.offsets[i]; j < hits.offsets[i + 1]; ++j) result_map[recs[i].id].insert(hits.leaves[j]);
-            for (uint64_t i = b0; i < b1; ++i) {
-                std::string s = recs[i].seq;
-                for (auto &c : s) c = (char)toupper((unsigned char)c);  // to_ascii_uppercase, main.rs:347-349
-                auto it = result_map.find(recs[i].id);
-                FILE *f = nullptr;
-                std::string id = recs[i].id;
-                if (it != result_map.end()) {  // read_mapped
-                    f = pos_f;
-                    id += " |";                // get_ext_id: "{id} |{g1,g2}" (set order unspecified in the reference)
-                    bool first = true;
-                    for (uint32_t leaf : it->second) {
-                        if (!first) id += ",";
-                        id += leaf_names[leaf];
-                        first = false;
+    });
+    for (int i = 0;; i ^= 1) {
+        int state;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return ready[i] != 0; });
+            state = ready[i];
+        }
+        Batch &b = batches[i];
+        const uint64_t n = b.n();
+        if (n) {
+            b.seq.resize(b.seq.size() + 16);
+            pfq_hits hits{};
+            check(pfq_query_batch(tree, b.seq.data(), b.off.data(), n, threshold, filtering ? PFQ_WANT_HITS : 0,
+                                  filtering ? &hits : nullptr));
+            if (filtering) {
+                std::string line;
+                for (uint64_t b0 = 0; b0 < n; b0 += block) {
+                    const uint64_t b1 = std::min(n, b0 + block);
+                    std::map<std::string, std::set<uint32_t>> result_map;  // read id -> leaf set (result_map.rs:20-22)
+                    for (uint64_t r = b0; r < b1; ++r)
+                        for (uint64_t j = hits.offsets[r]; j < hits.offsets[r + 1]; ++j) result_map[b.ids[r]].insert(hits.leaves[j]);
+                    for (uint64_t r = b0; r < b1; ++r) {
+                        auto it = result_map.empty() ? result_map.end() : result_map.find(b.ids[r]);
+                        FILE *f = it != result_map.end() ? pos_f : neg_f;  // read_mapped
+                        if (!f) continue;
+                        line.clear();
+                        line += b.has_qual[r] ? '@' : '>';  // write_record (main.rs:394-404)
+                        line += b.ids[r];
+                        if (it != result_map.end()) {       // get_ext_id: "{id} |{g1,g2}" (set order unspecified in the reference)
+                            line += " |";
+                            bool first = true;
+                            for (uint32_t leaf : it->second) {
+                                if (!first) line += ',';
+                                line += leaf_names[leaf];
+                                first = false;
+                            }
+                        }
+                        line += '\n';
+                        const size_t s0 = line.size();
+                        line.append((const char *)b.seq.data() + b.off[r], b.off[r + 1] - b.off[r]);
+                        for (size_t c = s0; c < line.size(); ++c) line[c] = (char)toupper((unsigned char)line[c]);  // main.rs:347-349
+                        line += '\n';
+                        if (b.has_qual[r]) {
+                            line += "+\n";
+                            line.append(b.qual.data() + b.off[r], b.off[r + 1] - b.off[r]);
+                            line += '\n';
+                        }
+                        fwrite(line.data(), 1, line.size(), f);
                     }
-                } else f = neg_f;
-                if (!f) continue;
-                if (recs[i].has_qual) fprintf(f, "@%s\n%s\n+\n%s\n", id.c_str(), s.c_str(), recs[i].qual.c_str());  // write_record
-                else fprintf(f, ">%s\n%s\n", id.c_str(), s.c_str());
+                }
             }
         }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ready[i] = 0;
+        }
+        cv.notify_all();
+        if (state == 2) break;
     }
+    parser.join();
     if (pos_f) fclose(pos_f);
     if (neg_f) fclose(neg_f);
     check(pfq_save_leaf_counts(tree, (out + "/CLASSIFICATION.csv").c_str()));
@@ -491,15 +568,11 @@ int cmd_build_balanced(int argc, char **argv) {
     const uint64_t s1 = strtoull(opt(a, "seed1", "81985529216486895").c_str(), nullptr, 0);
     const uint64_t s2 = strtoull(opt(a, "seed2", "18364758544493064720").c_str(), nullptr, 0);
     ReadQueue rq(genomes, to_fmt(opt(a, "format", "auto")));
-    std::vector<uint8_t> seq;
-    std::vector<uint64_t> off{0};
-    std::vector<std::string> ids;
-    Record r;
-    while (rq.next(r)) {  // block size 1 in the reference: one leaf per record (main.rs:148-200)
-        seq.insert(seq.end(), r.seq.begin(), r.seq.end());
-        off.push_back(seq.size());
-        ids.push_back(r.id);
-    }
+    Batch g;
+    while (rq.next(g, true)) {}  // block size 1 in the reference: one leaf per record (main.rs:148-200)
+    std::vector<uint8_t> &seq = g.seq;
+    std::vector<uint64_t> &off = g.off;
+    std::vector<std::string> &ids = g.ids;
     std::vector<const char *> idp;
     for (auto &s : ids) idp.push_back(s.c_str());
     const uint64_t nbits = needed_bits(fpr, largest);
