@@ -350,8 +350,8 @@ int build_layout(pfq_tree &t) {
     for (uint32_t r : guard_rows) t.col_row.push_back(r);
     t.n_cols = (uint32_t)t.col_row.size();
     uint32_t need_words = std::max<uint32_t>(1, (t.n_cols + 31) / 32);
-    t.rw = 1;
-    t.rw_log2 = 0;
+    t.rw = 4;  // at least 16-byte rows: the dense pre-screen gathers rows with dwordx4 loads
+    t.rw_log2 = 2;
     while (t.rw < need_words) {
         t.rw <<= 1;
         ++t.rw_log2;
@@ -400,7 +400,7 @@ int ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads) {
     HIP_TRY(t.d_pairs.ensure(cap));
     HIP_TRY(t.d_sorted.ensure(cap));
     HIP_TRY(t.d_fail.ensure(cap));
-    HIP_TRY(t.d_bucket.ensure(3 * t.leaves.size() + 2));
+    HIP_TRY(t.d_bucket.ensure(3 * (t.leaves.size() << 6) + 2));  // up to 64 sub-buckets per leaf
     HIP_TRY(t.d_queue.ensure(128));
     return PFQ_OK;
 }
@@ -464,11 +464,16 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             }
             if (ev) HIP_TRY(hipEventRecord(ev[0], st));
             if (bucketed) {
-                uint32_t *cnt = t.d_bucket.p, *off = cnt + nl, *cur = off + nl + 1;
+                // sub-buckets (keyed by the read index) keep every histogram counter cold when leaves are few
+                uint32_t sub_log2 = 0;
+                while (sub_log2 < 6 && (nl << sub_log2) < 1024) ++sub_log2;
+                const size_t nb = nl << sub_log2;
+                uint32_t *cnt = t.d_bucket.p, *off = cnt + nb, *cur = off + nb + 1;
                 a.pairs = t.d_pairs.p;
                 a.pair_cap = t.d_pairs.n & ~31ull;  // whole reservations only (PAIR_CHUNK = 32)
                 a.pair_cursor = t.d_cursors.p + 1;
                 a.bucket_cnt = cnt;
+                a.sub_log2 = sub_log2;
                 // probe records: hash survivors once instead of once per slice (needs d < 2^30, <= 35 hashes, room)
                 uint4 *recs = nullptr;
                 uint64_t rec_budget = 64ull << 30;
@@ -485,13 +490,13 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 if (const char *e = getenv("PFQ_SLICE_KB")) slice_target = strtoull(e, nullptr, 10) << 10;
                 while (n_slices < 8 && (t.n_words * 8 + n_slices - 1) / n_slices > slice_target) n_slices <<= 1;
                 t.last_slices = n_slices;
-                HIP_TRY(hipMemsetAsync(cnt, 0, nl * 4, st));
+                HIP_TRY(hipMemsetAsync(cnt, 0, nb * 4, st));
                 HIP_TRY(hipMemsetAsync(t.d_fail.p, 0, t.d_fail.n * 4, st));
                 HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 128 * 4, st));
                 pfq::launch_classify(a, true, false, blocks, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
-                pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nl, st);
-                pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, t.d_sorted.p,
+                pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nb, st);
+                pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, sub_log2, t.d_sorted.p,
                                            recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, 1024, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[2], st));
                 pfq::VerifyArgs v{};
@@ -502,7 +507,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 v.col_row = t.d_col_row.p;
                 v.n_words = t.n_words;
                 v.sorted = t.d_sorted.p;
-                v.n_pairs_ptr = off + nl;
+                v.n_pairs_ptr = off + nb;
                 v.fail = t.d_fail.p;
                 v.recs = recs;
                 v.meta = t.d_meta.p;
@@ -527,6 +532,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 f.off = d_off;
                 f.sorted = t.d_sorted.p;
                 f.bucket_off = off;
+                f.sub_log2 = sub_log2;
                 f.fail = t.d_fail.p;
                 f.n_leaves = (uint32_t)nl;
                 f.counts = t.d_counts.p;

@@ -39,7 +39,8 @@ struct QueryArgs {
     uint2 *pairs;
     uint64_t pair_cap;
     unsigned long long *pair_cursor;
-    uint32_t *bucket_cnt;        // [n_leaves]
+    uint32_t *bucket_cnt;        // [n_leaves << sub_log2]: bucket = (leaf << sub_log2) | (read & (subs-1))
+    uint32_t sub_log2;           // sub-buckets per leaf (so that no counter is a hot spot when leaves are few)
     uint4 *recs;                 // probe records, indexed by (read byte offset + k-mer position), or nullptr
     uint64_t rec_cap;            // entries in recs (reads whose records would not fit are certified inline)
 };
@@ -66,7 +67,8 @@ struct FinalizeArgs {
     HashParams hp;
     const uint64_t *off;
     const uint2 *sorted;
-    const uint32_t *bucket_off;  // [n_leaves+1]
+    const uint32_t *bucket_off;  // [(n_leaves << sub_log2) + 1]
+    uint32_t sub_log2;
     const uint32_t *fail;
     uint32_t n_leaves;
     unsigned long long *counts;
@@ -80,7 +82,7 @@ struct FinalizeArgs {
 void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int blocks, hipStream_t st);
 void launch_bucket_scan(const uint32_t *bucket_cnt, uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t n, hipStream_t st);
 void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
-                           const uint32_t *bucket_off, uint32_t *bucket_cur, uint2 *sorted, uint4 *meta,
+                           const uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t sub_log2, uint2 *sorted, uint4 *meta,
                            const uint64_t *read_off, const uint32_t *col_row, int blocks, hipStream_t st);
 void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st);
 void launch_finalize(const FinalizeArgs &a, hipStream_t st);

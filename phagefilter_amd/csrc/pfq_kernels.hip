@@ -19,6 +19,7 @@ namespace pfq {
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((31u << 11) | 20u) & 0xFu; }
 
 constexpr uint32_t SCREEN_ROUNDS = 2;  // row loads in flight per lane and probe in the theta=1 screen
+constexpr uint32_t SCREEN_KMERS = 4;   // k-mers the theta=1 screen looks at (rows of narrow trees would allow more per load)
 constexpr uint32_t PAIR_CHUNK = 32;    // slots a wave reserves at a time in the deferred-pair buffer
 constexpr uint32_t NPLANES = 16;       // vertical-counter planes of the theta<1 screen (k-mers per read < 65536)
 
@@ -73,7 +74,7 @@ __device__ __forceinline__ uint32_t screen_all(BlockLds &lds, uint32_t wave, con
 #pragma unroll
     for (uint32_t j = 0; j < SCREEN_ROUNDS; ++j) {
         uint32_t kk = j * slots + slot;
-        bool valid = kk < cnt;
+        bool valid = kk < cnt && kk < SCREEN_KMERS;  // four k-mers x two probes empty the frontier of a foreign read
         uint32_t src = valid ? kk : 0u;
         uint32_t r0 = (uint32_t)__shfl((int)i0, (int)src), r1 = (uint32_t)__shfl((int)i1, (int)src);
         v0[j] = valid ? a.S[(uint64_t)r0 * rw + word] : ~0u;
@@ -316,7 +317,7 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
                 if (pair_used < PAIR_CHUNK) {
                     if (lane == 0) {
                         a.pairs[pair_base + pair_used] = make_uint2((uint32_t)r, col);
-                        atomicAdd(&a.bucket_cnt[col], 1u);
+                        atomicAdd(&a.bucket_cnt[(col << a.sub_log2) | ((uint32_t)r & ((1u << a.sub_log2) - 1u))], 1u);
                     }
                     ++pair_used;
                     ++st_def;
@@ -428,14 +429,16 @@ void launch_bucket_scan(const uint32_t *bucket_cnt, uint32_t *bucket_off, uint32
 // Scatter into leaf order; `meta` gets everything the record-driven verify needs about a pair in one 16-byte
 // entry (read byte offset, read length, filter row) so that kernel has no dependent metadata loads.
 __global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr,
-                                                        uint64_t pair_cap, const uint32_t *off, uint32_t *cur, uint2 *sorted,
-                                                        uint4 *meta, const uint64_t *read_off, const uint32_t *col_row) {
+                                                        uint64_t pair_cap, const uint32_t *off, uint32_t *cur, uint32_t sub_log2,
+                                                        uint2 *sorted, uint4 *meta, const uint64_t *read_off,
+                                                        const uint32_t *col_row) {
     uint64_t n = *n_pairs_ptr;
     if (n > pair_cap) n = pair_cap;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint2 p = pairs[i];
         if (p.y == 0xffffffffu) continue;  // voided slot of a partially used reservation
-        uint32_t pos = off[p.y] + atomicAdd(&cur[p.y], 1u);
+        const uint32_t bkt = (p.y << sub_log2) | (p.x & ((1u << sub_log2) - 1u));
+        uint32_t pos = off[bkt] + atomicAdd(&cur[bkt], 1u);
         sorted[pos] = p;
         if (meta) {
             uint64_t o0 = read_off[p.x], L = read_off[p.x + 1] - o0;
@@ -444,10 +447,10 @@ __global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, cons
     }
 }
 void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
-                           const uint32_t *bucket_off, uint32_t *bucket_cur, uint2 *sorted, uint4 *meta,
+                           const uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t sub_log2, uint2 *sorted, uint4 *meta,
                            const uint64_t *read_off, const uint32_t *col_row, int blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, pairs, n_pairs_ptr, pair_cap, bucket_off, bucket_cur,
-                       sorted, meta, read_off, col_row);
+                       sub_log2, sorted, meta, read_off, col_row);
 }
 
 // ---- K2 for bucketed survivors: L2-resident filter slices ------------------------------------------------------------
@@ -636,7 +639,7 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
         if (threadIdx.x == 0) { s_cnt = 0; s_bytes = 0; }
         __syncthreads();
         unsigned long long cnt = 0, bytes = 0;
-        for (uint32_t e = a.bucket_off[c] + threadIdx.x; e < a.bucket_off[c + 1]; e += blockDim.x) {
+        for (uint32_t e = a.bucket_off[c << a.sub_log2] + threadIdx.x; e < a.bucket_off[(c + 1) << a.sub_log2]; e += blockDim.x) {
             if (!a.fail[e]) {
                 uint2 p = a.sorted[e];
                 uint64_t L = a.off[p.x + 1] - a.off[p.x];
