@@ -168,7 +168,8 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg},
             "query_path": "bucketed(screen+L2-sliced verify)" if st.path == 1 else "direct",
-            "n_slices": int(st.n_slices),
+            "n_slices": int(st.n_slices), "tile_mode": int(st.tile_mode), "fallback_pairs": int(st.n_fallback_pairs),
+            "tile_chunks": int(st.n_chunks), "tile_entries": int(st.tile_entries),
             "kernel_ms_per_step": {k: v / max(prof.calls, 1) for k, v in kern.items()},
             "hits_total": total_hits, "hits_last_step": int(st.n_hits), "candidates_last_step": int(st.n_candidates),
             "setup_seconds": setup_s,

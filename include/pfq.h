@@ -137,6 +137,9 @@ typedef struct pfq_stats {
     uint64_t algorithmic_bytes; /* sum_r L(r) + |hits(r)| * need(r) * num_hashes * 32 */
     uint32_t path;              /* 0 = direct kernel, 1 = bucketed (screen + L2-sliced verify) */
     uint32_t n_slices;
+    uint32_t tile_mode;         /* 1: certificates tested out of LDS tiles (k_tile_*), k_verify_rec only as fallback */
+    uint32_t n_fallback_pairs;  /* pairs the LDS-tile pass could not bin (certified by the fallback kernel) */
+    uint64_t n_chunks, tile_entries;
 } pfq_stats;
 int pfq_last_stats(pfq_tree *tree, pfq_stats *out);
 /* Force a query path: -1 auto, 0 direct, 1 bucketed. */

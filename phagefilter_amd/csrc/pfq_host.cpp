@@ -98,7 +98,11 @@ struct pfq_tree {
     DevBuf<uint32_t> d_S, d_col_row, d_guard_off, d_guard_col;
     DevBuf<unsigned long long> d_counts;
     // ---- query scratch
-    DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit cursor, [1] pair cursor
+    DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit, [1] pair, [2] tile entries, [3] lo: chunks, hi: flagged pairs
+    DevBuf<uint32_t> d_entries, d_pair_chunk, d_leaf_chunk0, d_flag_list;  // LDS-tile certificates
+    DevBuf<pfq::ChunkDesc> d_chunks;
+    DevBuf<unsigned int> d_gfill;
+    uint32_t last_tile_mode = 0;
     DevBuf<uint2> d_hit_pairs, d_pairs, d_sorted;
     DevBuf<uint32_t> d_bucket, d_fail;  // bucket: cnt[n], off[n+1], cur[n]
     DevBuf<unsigned int> d_queue;
@@ -386,7 +390,7 @@ int build_layout(pfq_tree &t) {
 
 int ensure_scratch(pfq_tree &t, uint64_t n_reads, bool want_hits) {
     HIP_TRY(t.d_stats.ensure(pfq::ST_N));
-    HIP_TRY(t.d_cursors.ensure(2));
+    HIP_TRY(t.d_cursors.ensure(4));
     const uint64_t cap = 2 * n_reads + 1024;
     if (want_hits) {
         HIP_TRY(t.d_hit_pairs.ensure(cap));
@@ -428,7 +432,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     uint64_t hit_cap = t.d_hit_pairs.n;
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIP_TRY(hipMemsetAsync(t.d_stats.p, 0, pfq::ST_N * 8, st));
-        HIP_TRY(hipMemsetAsync(t.d_cursors.p, 0, 16, st));
+        HIP_TRY(hipMemsetAsync(t.d_cursors.p, 0, 32, st));
         if (want_hits) {
             HIP_TRY(hipMemsetAsync(t.d_allhit.p, 0, n_reads + 1, st));
             if (attempt == 0 && nl)
@@ -525,6 +529,66 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 int vthreads = 512;
                 if (const char *e = getenv("PFQ_VERIFY_THREADS")) vthreads = std::min(1024, std::max(64, atoi(e) & ~63));
                 if (!recs) { vthreads = 256; vblocks = 1024; v.chunk = 4; }  // re-hash fallback kernel: 4-wave blocks
+                // LDS-tile certificates: every probe binned by (leaf chunk, 128 KiB filter tile), tiles tested out of LDS;
+                // k_verify_rec then only sees the pairs that could not be binned
+                const uint32_t n_tiles = (uint32_t)((t.n_words * 64 + (1ull << pfq::TILE_LOG2) - 1) >> pfq::TILE_LOG2);
+                bool tile_mode = recs && n_tiles <= pfq::MAX_TILES;
+                if (const char *e = getenv("PFQ_TILE")) tile_mode = tile_mode && atoi(e) != 0;
+                uint64_t tile_budget = 64ull << 30;
+                if (const char *e = getenv("PFQ_TILE_GB")) tile_budget = strtoull(e, nullptr, 10) << 30;
+                t.last_tile_mode = 0;
+                if (tile_mode) {
+                    // every read may survive with one candidate: (bases - (k-1) per read) * hashes * 1.125 + slack per bucket
+                    const uint64_t max_chunks = nl + (a.pair_cap >> pfq::CHUNK_PAIRS_LOG2) + 2;
+                    uint64_t want = (uint64_t)((double)total_bytes * t.num_hashes * 1.13) + max_chunks * n_tiles * 544ull;
+                    if (want * 4 > tile_budget) want = tile_budget / 4;
+                    hipError_t e1 = t.d_entries.ensure(want);
+                    if (e1 != hipSuccess) {
+                        (void)hipGetLastError();
+                        tile_mode = false;  // not enough HBM for the probe buckets: stay with the record kernel
+                    } else {
+                        HIP_TRY(t.d_pair_chunk.ensure(t.d_pairs.n));
+                        HIP_TRY(t.d_flag_list.ensure(t.d_pairs.n));
+                        HIP_TRY(t.d_leaf_chunk0.ensure(nl + 1));
+                        HIP_TRY(t.d_chunks.ensure(max_chunks));
+                        HIP_TRY(t.d_gfill.ensure(max_chunks * n_tiles));
+                        HIP_TRY(hipMemsetAsync(t.d_gfill.p, 0, max_chunks * n_tiles * 4, st));
+                        pfq::TileArgs ta{};
+                        ta.hp = t.hp;
+                        ta.bits = t.d_bits.p;
+                        ta.n_words = t.n_words;
+                        ta.recs = recs;
+                        ta.meta = t.d_meta.p;
+                        ta.bucket_off = off;
+                        ta.sub_log2 = sub_log2;
+                        ta.n_leaves = (uint32_t)nl;
+                        ta.n_tiles = n_tiles;
+                        ta.chunks = t.d_chunks.p;
+                        ta.max_chunks = (uint32_t)max_chunks;
+                        ta.leaf_chunk0 = t.d_leaf_chunk0.p;
+                        ta.pair_chunk = t.d_pair_chunk.p;
+                        ta.n_chunks = reinterpret_cast<unsigned int *>(t.d_cursors.p + 3);
+                        ta.n_flagged = reinterpret_cast<unsigned int *>(t.d_cursors.p + 3) + 1;
+                        ta.flag_list = t.d_flag_list.p;
+                        ta.flag_cap = (uint32_t)std::min<uint64_t>(t.d_flag_list.n, 0xffffffffu);
+                        ta.entry_cursor = t.d_cursors.p + 2;
+                        ta.entry_cap = t.d_entries.n;
+                        ta.entries = t.d_entries.p;
+                        ta.gfill = t.d_gfill.p;
+                        ta.fail = t.d_fail.p;
+                        ta.n_pairs_ptr = off + nb;
+                        int bin_blocks = 512, test_blocks = 512;
+                        if (const char *e = getenv("PFQ_BIN_BLOCKS")) bin_blocks = std::max(1, atoi(e));
+                        if (const char *e = getenv("PFQ_TEST_BLOCKS")) test_blocks = std::max(1, atoi(e));
+                        pfq::launch_tile_plan(ta, st);
+                        pfq::launch_tile_bin(ta, bin_blocks, st);
+                        pfq::launch_tile_test(ta, test_blocks, st);
+                        v.only_flagged = 1;
+                        v.n_flagged = ta.n_flagged;
+                        v.flag_list = t.d_flag_list.p;
+                        t.last_tile_mode = 1;
+                    }
+                }
                 pfq::launch_verify(v, vblocks, vthreads, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[3], st));
                 pfq::FinalizeArgs f{};
@@ -921,7 +985,7 @@ int pfq_tree_info(const pfq_tree *tree, pfq_info *out) {
     out->shard_first_leaf = t.shard_first_leaf;
     out->tree_leaves = t.is_shard ? t.tree_leaves : out->n_leaves;
     out->device_bytes = t.d_bits.bytes() + t.d_S.bytes() + t.d_pairs.bytes() + t.d_sorted.bytes() + t.d_fail.bytes() +
-                        t.d_hit_pairs.bytes() + t.d_seq.bytes() + t.d_off.bytes() + t.d_recs.bytes();
+                        t.d_hit_pairs.bytes() + t.d_seq.bytes() + t.d_off.bytes() + t.d_recs.bytes() + t.d_entries.bytes();
     return PFQ_OK;
 }
 
@@ -1044,6 +1108,14 @@ int pfq_last_stats(pfq_tree *tree, pfq_stats *out) {
     out->algorithmic_bytes = h[pfq::ST_ALG_BYTES];
     out->path = t.last_path;
     out->n_slices = t.last_slices;
+    out->tile_mode = t.last_tile_mode;
+    if (t.d_cursors.p) {
+        unsigned long long c[4];
+        HIP_TRY(hipMemcpy(c, t.d_cursors.p, sizeof c, hipMemcpyDeviceToHost));
+        out->n_chunks = (uint32_t)c[3];
+        out->n_fallback_pairs = (uint32_t)(c[3] >> 32);
+        out->tile_entries = c[2];
+    }
     return PFQ_OK;
 }
 int pfq_profile_begin(pfq_tree *tree, uint32_t max_calls) {

@@ -59,6 +59,9 @@ struct VerifyArgs {
     uint32_t n_slices, slice_bits;
     unsigned int *queue;         // work cursors: [n_slices] (re-hash kernel) / [8 * n_sub] (record kernel)
     uint32_t n_sub;              // sub-queues per XCD (record kernel)
+    uint32_t only_flagged;       // 1: only pairs whose fail word has bit 1 set (fallback after the LDS-tile pass)
+    const unsigned int *n_flagged;  // number of such pairs (kernel returns at once when 0)
+    const uint32_t *flag_list;      // their sorted-pair indices
     const uint4 *recs;           // probe records written by k_classify<DEFER> (nullptr: re-hash per slice)
     uint32_t chunk;
 };
@@ -77,6 +80,48 @@ struct FinalizeArgs {
     unsigned long long *hit_cursor;
     unsigned long long *stats;
 };
+
+// ---- LDS-tile certificates (bucketed path, records available) ------------------------------------------------------
+// Every probe of every sorted pair is binned by (chunk of <= 4096 pairs of one leaf, 2^20-bit tile of the filter);
+// a block then loads one tile of one leaf into LDS and tests all its probes there.
+constexpr uint32_t TILE_LOG2 = 19;                 // bits per tile = 64 KiB of filter (two test blocks per CU)
+constexpr uint32_t CHUNK_PAIRS_LOG2 = 13;          // pairs per chunk: local pair id and tile offset share one u32 entry
+constexpr uint32_t MAX_TILES = 256;                // filters up to 2^27 bits take this path
+struct ChunkDesc {
+    uint32_t row;      // filter row of the leaf
+    uint32_t first;    // first sorted pair
+    uint32_t n;        // pairs
+    uint32_t cap;      // entries per (chunk, tile) bucket; 0: no room, the chunk's pairs take the fallback
+    uint64_t base;     // first entry of tile 0's bucket
+    uint32_t leaf;
+    uint32_t pad;
+};
+struct TileArgs {
+    HashParams hp;
+    const uint64_t *bits;
+    uint64_t n_words;
+    const uint4 *recs;
+    const uint4 *meta;           // per sorted pair (read offset lo, hi, length, row)
+    const uint32_t *bucket_off;  // [(n_leaves << sub_log2) + 1]
+    uint32_t sub_log2, n_leaves, n_tiles;
+    ChunkDesc *chunks;           // [max_chunks]
+    uint32_t max_chunks;
+    uint32_t *leaf_chunk0;       // [n_leaves + 1] first chunk of each leaf (chunks of a leaf are contiguous)
+    uint32_t *pair_chunk;        // [pair_cap] chunk of each sorted pair
+    unsigned int *n_chunks;      // counter
+    unsigned long long *entry_cursor;
+    uint64_t entry_cap;
+    uint32_t *entries;
+    unsigned int *gfill;         // [max_chunks * n_tiles]
+    uint32_t *fail;              // bit 0: a probed bit was 0; bit 1: pair must be verified by the fallback kernel
+    unsigned int *n_flagged;     // pairs with bit 1
+    uint32_t *flag_list;         // [flag_cap] their sorted-pair indices
+    uint32_t flag_cap;
+    const uint32_t *n_pairs_ptr;
+};
+void launch_tile_plan(const TileArgs &a, hipStream_t st);
+void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st);
+void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st);
 
 // launches (all asynchronous on `st`)
 void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int blocks, hipStream_t st);

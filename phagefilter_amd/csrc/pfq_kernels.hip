@@ -520,7 +520,9 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs a) {
 __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
     __shared__ uint32_t s_item[2];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint64_t n_pairs = *a.n_pairs_ptr;
+    if (a.only_flagged && *a.n_flagged == 0) return;  // the LDS-tile pass certified everything
+    // fallback mode: the work list is the compact list of flagged pairs, not all sorted pairs
+    const uint64_t n_pairs = a.only_flagged ? *a.n_flagged : *a.n_pairs_ptr;
     // an item = (waves per block) x chunk consecutive pairs, pulled with ONE queue atomic (a same-address returning
     // atomic costs ~90 ns at the memory side, so items must be large) while the pairs in flight per XCD
     // (blocks per XCD x item) stay at about one leaf's share
@@ -529,9 +531,12 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
     const uint32_t home = xcc_id() & 7u, groups = 8u / a.n_slices;
     const uint32_t d = (uint32_t)a.hp.nbits, dw = d - (uint32_t)a.hp.w64, k = a.hp.k, nh = a.hp.num_hashes;
 
-    auto load_meta = [&](uint64_t it) -> uint4 {
-        const uint64_t e = it * item_pairs + (uint64_t)wave * per_wave + lane;
-        return (it < n_items && lane < per_wave && e < n_pairs) ? a.meta[e] : make_uint4(0, 0, 0, 0);
+    auto pair_index = [&](uint64_t i) -> uint32_t { return a.only_flagged ? a.flag_list[i] : (uint32_t)i; };
+    auto load_meta = [&](uint64_t it, uint32_t &e_idx) -> uint4 {
+        const uint64_t i = it * item_pairs + (uint64_t)wave * per_wave + lane;
+        const bool ok = it < n_items && lane < per_wave && i < n_pairs;
+        e_idx = ok ? pair_index(i) : 0u;
+        return ok ? a.meta[e_idx] : make_uint4(0, 0, 0, 0);
     };
 
     // Every XCD's item sequence is dealt round-robin to n_sub sub-queues (own counter each) so that no counter
@@ -552,12 +557,13 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
         __syncthreads();
         uint64_t it_cur = (uint64_t)s_item[0] * stride + first, it_nxt = (uint64_t)s_item[1] * stride + first;
         __syncthreads();
-        uint4 meta_cur = load_meta(it_cur);
+        uint32_t idx_cur, idx_nxt;
+        uint4 meta_cur = load_meta(it_cur, idx_cur);
         uint32_t buf = 0;
         while (it_cur < n_items) {
             uint32_t pend = 0;
             if (threadIdx.x == 0) pend = atomicAdd(qctr, 1u);  // item t+2
-            const uint4 meta_nxt = load_meta(it_nxt);                   // item t+1
+            const uint4 meta_nxt = load_meta(it_nxt, idx_nxt);          // item t+1
             const uint64_t e0 = it_cur * item_pairs + (uint64_t)wave * per_wave;
             const uint32_t W = e0 >= n_pairs ? 0u : (uint32_t)(e0 + per_wave < n_pairs ? per_wave : n_pairs - e0);
             for (uint32_t j = 0; j < W; ++j) {
@@ -615,7 +621,7 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
                     }
                     miss = miss || !(ok & 1u);
                 }
-                if (ballot64(miss) && lane == 0) a.fail[e0 + j] = 1u;
+                if (ballot64(miss) && lane == 0) atomicOr(&a.fail[bcast_u32(idx_cur, j)], 1u);
             }
             if (threadIdx.x == 0) s_item[buf] = pend;
             __syncthreads();
@@ -623,10 +629,243 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
             buf ^= 1u;
             it_cur = it_nxt;
             meta_cur = meta_nxt;
+            idx_cur = idx_nxt;
             it_nxt = it_new;
         }
     }
 }
+// ---- LDS-tile certificates ------------------------------------------------------------------------------------------------
+// (1) plan: one block per leaf cuts the leaf's sorted pairs into chunks of <= 4096, sizes the chunk's per-tile
+//     buckets from its k-mer count and reserves them; (2) bin: blocks walk the sorted pairs, regenerate every probe
+//     index from the records and append (local pair, offset in tile) to LDS bins, flushed per round to the
+//     (chunk, tile) buckets in full runs; (3) test: a block loads one tile of one leaf into LDS (128 KiB) and tests
+//     all probes binned for it.  A probe found 0 sets bit 0 of the pair's fail word.  Whatever cannot be binned
+//     (bucket or entry buffer full) sets bit 1: those pairs are certified by k_verify_rec afterwards.
+__global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
+    __shared__ unsigned long long s_sum;
+    __shared__ uint32_t s_chunk0;
+    const uint32_t c = blockIdx.x;
+    const uint32_t lo = a.bucket_off[c << a.sub_log2], hi = a.bucket_off[(c + 1) << a.sub_log2];
+    const uint32_t n_ch = (hi - lo + (1u << CHUNK_PAIRS_LOG2) - 1u) >> CHUNK_PAIRS_LOG2;
+    if (threadIdx.x == 0) {
+        s_chunk0 = n_ch ? atomicAdd(a.n_chunks, n_ch) : 0u;
+        a.leaf_chunk0[c] = n_ch ? s_chunk0 : 0xffffffffu;
+    }
+    __syncthreads();
+    const uint32_t chunk0 = s_chunk0;
+    for (uint32_t ci = 0; ci < n_ch; ++ci) {
+        const uint32_t first = lo + (ci << CHUNK_PAIRS_LOG2), n = (hi - first) < (1u << CHUNK_PAIRS_LOG2) ? hi - first : (1u << CHUNK_PAIRS_LOG2);
+        if (threadIdx.x == 0) s_sum = 0;
+        __syncthreads();
+        unsigned long long kmers = 0;
+        const uint32_t chunk = chunk0 + ci;
+        for (uint32_t e = first + threadIdx.x; e < first + n; e += blockDim.x) {
+            kmers += a.meta[e].z - a.hp.k + 1;
+            a.pair_chunk[e] = chunk < a.max_chunks ? chunk : 0xffffffffu;
+        }
+        for (int d = 32; d > 0; d >>= 1) kmers += __shfl_down(kmers, d);
+        if (lane_id() == 0 && kmers) atomicAdd(&s_sum, kmers);
+        __syncthreads();
+        if (threadIdx.x == 0 && chunk < a.max_chunks) {
+            // mean probes per tile + 12.5 % + slack (a uniform hash stays far below; anything beyond falls back)
+            unsigned long long mean = (s_sum * a.hp.num_hashes + a.n_tiles - 1) / a.n_tiles;
+            uint32_t cap = (uint32_t)((mean + (mean >> 3) + 512 + 31) & ~31ull);
+            unsigned long long need = (unsigned long long)cap * a.n_tiles;
+            unsigned long long base = atomicAdd(a.entry_cursor, need);
+            ChunkDesc dsc;
+            dsc.row = a.meta[first].w;
+            dsc.first = first;
+            dsc.n = n;
+            dsc.cap = (base + need <= a.entry_cap) ? cap : 0u;
+            dsc.base = base;
+            dsc.leaf = c;
+            dsc.pad = 0;
+            a.chunks[chunk] = dsc;
+        }
+        __syncthreads();
+    }
+}
+void launch_tile_plan(const TileArgs &a, hipStream_t st) {
+    if (a.n_leaves) hipLaunchKernelGGL(k_tile_plan, dim3(a.n_leaves), dim3(256), 0, st, a);
+}
+
+constexpr uint32_t BIN_WAVES = 8;       // pairs binned per round by one block
+constexpr uint32_t BIN_CAP = 128;       // LDS entries per tile and round (mean ~75 at 150 bp / 138 tiles)
+constexpr uint32_t NO_PAIR = 0xfffffffeu;
+__device__ __forceinline__ void flag_fallback(const TileArgs &a, uint32_t e) {
+    if (!(atomicOr(&a.fail[e], 2u) & 2u)) {
+        const uint32_t pos = atomicAdd(a.n_flagged, 1u);
+        if (pos < a.flag_cap) a.flag_list[pos] = e;
+    }
+}
+__global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
+    extern __shared__ uint32_t s_dyn[];   // cnt[MAX_TILES] then bins[n_tiles][BIN_CAP]
+    __shared__ uint32_t s_wc[BIN_WAVES];
+    __shared__ uint32_t s_pos[MAX_TILES];
+    uint32_t *cnt = s_dyn, *bins = s_dyn + MAX_TILES;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t n_pairs = *a.n_pairs_ptr;
+    const uint32_t d = (uint32_t)a.hp.nbits, dw = d - (uint32_t)a.hp.w64, k = a.hp.k, nh = a.hp.num_hashes;
+    // a block takes rounds of BIN_WAVES consecutive sorted pairs, one pair per wave; the pairs of a round that
+    // belong to the same chunk are binned together (normally all of them), chunk after chunk
+    const uint32_t n_rounds = (n_pairs + BIN_WAVES - 1) / BIN_WAVES;
+    for (uint32_t rd = blockIdx.x; rd < n_rounds; rd += gridDim.x) {
+        const uint32_t e = rd * BIN_WAVES + wave;
+        const bool have = e < n_pairs;
+        uint32_t my_chunk = have ? a.pair_chunk[e] : NO_PAIR;
+        if (have && my_chunk == 0xffffffffu) {  // chunk table full: fallback
+            if (lane == 0) flag_fallback(a, e);
+            my_chunk = NO_PAIR;
+        }
+        __syncthreads();
+        if (lane == 0) s_wc[wave] = my_chunk;
+        __syncthreads();
+        uint32_t pending = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < BIN_WAVES; ++w) pending |= (s_wc[w] != NO_PAIR ? 1u : 0u) << w;
+        while (pending) {
+            const uint32_t cur = s_wc[__ffs((int)pending) - 1];
+#pragma unroll
+            for (uint32_t w = 0; w < BIN_WAVES; ++w)
+                if (s_wc[w] == cur) pending &= ~(1u << w);
+            for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) cnt[t] = 0;
+            __syncthreads();
+            const ChunkDesc dsc = a.chunks[cur];
+            if (my_chunk == cur) {
+                if (dsc.cap == 0) {
+                    if (lane == 0) flag_fallback(a, e);  // no bucket space for this chunk
+                } else {
+                    const uint4 m = a.meta[e];
+                    const uint64_t o0 = ((uint64_t)m.y << 32) | m.x, n = (uint64_t)m.z - k + 1;
+                    const uint32_t local = (e - dsc.first) << TILE_LOG2;
+                    const uint4 *rp = a.recs + o0;
+                    bool spilled = false;
+                    for (uint64_t g0 = 0; g0 < n; g0 += 3 * WIN_KMERS) {  // three windows' records are loaded together
+                        uint4 rec[3];
+                        bool valid[3];
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) {
+                            const uint64_t q = g0 + 64u * w + lane;
+                            valid[w] = q < n;
+                            rec[w] = valid[w] ? rp[q] : make_uint4(0, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) {
+                            RecordIter rit;
+                            rit.init(rec[w]);
+                            auto put = [&](uint32_t idx) {
+                                if (!valid[w]) return;
+                                const uint32_t tile = idx >> TILE_LOG2, ent = local | (idx & ((1u << TILE_LOG2) - 1u));
+                                const uint32_t slot = atomicAdd(&cnt[tile], 1u);
+                                if (slot < BIN_CAP) bins[tile * BIN_CAP + slot] = ent;
+                                else spilled = true;  // LDS bin full: this pair goes to the fallback
+                            };
+                            put(rit.i0);
+                            if (nh > 1) put(rit.g);
+                            if (nh > 2) put(rit.x);
+                            for (uint32_t i = 3; i < nh; ++i) put(rit.step(d, dw));
+                        }
+                    }
+                    if (ballot64(spilled) && lane == 0) flag_fallback(a, e);
+                }
+            }
+            __syncthreads();
+            // flush: every tile's bin goes to its (chunk, tile) bucket as one run; all reservations of the round
+            // are made by one atomic instruction (one lane per tile), not tile after tile
+            if (dsc.cap) {
+                for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) {
+                    const uint32_t c = cnt[t] < BIN_CAP ? cnt[t] : BIN_CAP;
+                    s_pos[t] = c ? atomicAdd(&a.gfill[(uint64_t)cur * a.n_tiles + t], c) : 0u;
+                }
+                __syncthreads();
+                for (uint32_t t = wave; t < a.n_tiles; t += BIN_WAVES) {
+                    const uint32_t c = cnt[t] < BIN_CAP ? cnt[t] : BIN_CAP;
+                    if (c == 0) continue;
+                    const uint32_t pos = s_pos[t];
+                    uint32_t *dst = a.entries + dsc.base + (uint64_t)t * dsc.cap;
+                    if (pos + c <= dsc.cap) {
+                        for (uint32_t i = lane; i < c; i += 64) dst[pos + i] = bins[t * BIN_CAP + i];
+                    } else {  // bucket full: the pairs whose probes are dropped take the fallback
+                        for (uint32_t i = lane; i < c; i += 64) flag_fallback(a, dsc.first + (bins[t * BIN_CAP + i] >> TILE_LOG2));
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
+    size_t lds = (MAX_TILES + (size_t)a.n_tiles * BIN_CAP) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_tile_bin, dim3(blocks), dim3(BIN_WAVES * 64), lds, st, a);
+}
+
+__global__ void __launch_bounds__(512) k_tile_test(TileArgs a) {
+    extern __shared__ uint32_t s_tile[];  // 2^TILE_LOG2 bits
+    const uint32_t tile_words = 1u << (TILE_LOG2 - 5);
+    const uint64_t n_words32 = a.n_words * 2;
+    const uint64_t n_tasks = (uint64_t)a.n_leaves * a.n_tiles;
+    const uint32_t n_chunks = *a.n_chunks < a.max_chunks ? *a.n_chunks : a.max_chunks;
+    for (uint64_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const uint32_t leaf = (uint32_t)(task / a.n_tiles), t = (uint32_t)(task % a.n_tiles);
+        uint32_t ch = a.leaf_chunk0[leaf];
+        if (ch == 0xffffffffu) continue;  // no pairs for this leaf
+        __syncthreads();
+        // the leaf's tile: words [t * tile_words, ...) of its filter row (zero beyond the filter's end)
+        const uint32_t row = ch < n_chunks ? a.chunks[ch].row : 0u;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)row * a.n_words);
+        const uint64_t w0 = (uint64_t)t * tile_words;
+        // filter rows are only 8-byte aligned: 8-byte loads, eight in flight per thread
+        for (uint32_t i0 = threadIdx.x * 2; i0 < tile_words; i0 += blockDim.x * 16) {
+            uint2 v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + u * blockDim.x * 2;
+                v[u] = (i < tile_words && w0 + i + 1 < n_words32) ? *reinterpret_cast<const uint2 *>(src + w0 + i) : make_uint2(0, 0);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + u * blockDim.x * 2;
+                if (i < tile_words) *reinterpret_cast<uint2 *>(s_tile + i) = v[u];
+            }
+        }
+        __syncthreads();
+        for (; ch < n_chunks && a.chunks[ch].leaf == leaf; ++ch) {
+            const ChunkDesc dsc = a.chunks[ch];
+            if (!dsc.cap) continue;
+            uint32_t fill = a.gfill[(uint64_t)ch * a.n_tiles + t];
+            if (fill > dsc.cap) fill = dsc.cap;
+            const uint32_t *ent = a.entries + dsc.base + (uint64_t)t * dsc.cap;
+            for (uint32_t i0 = threadIdx.x; i0 < fill; i0 += blockDim.x * 8) {  // eight entries in flight per thread
+                uint32_t en[8];
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) {
+                    const uint32_t i = i0 + u * blockDim.x;
+                    en[u] = i < fill ? ent[i] : 0xffffffffu;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) {
+                    const uint32_t i = i0 + u * blockDim.x;
+                    const uint32_t off = en[u] & ((1u << TILE_LOG2) - 1u);
+                    if (i < fill && !((s_tile[off >> 5] >> (off & 31u)) & 1u)) atomicOr(&a.fail[dsc.first + (en[u] >> TILE_LOG2)], 1u);
+                }
+            }
+        }
+    }
+}
+void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_tile_test, dim3(blocks), dim3(512), (size_t)(1u << (TILE_LOG2 - 3)), st, a);
+}
+
 void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st) {
     if (a.recs) hipLaunchKernelGGL(k_verify_rec, dim3(blocks), dim3(threads), 0, st, a);
     else hipLaunchKernelGGL(k_verify, dim3(blocks), dim3(256), 0, st, a);
@@ -640,7 +879,7 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
         __syncthreads();
         unsigned long long cnt = 0, bytes = 0;
         for (uint32_t e = a.bucket_off[c << a.sub_log2] + threadIdx.x; e < a.bucket_off[(c + 1) << a.sub_log2]; e += blockDim.x) {
-            if (!a.fail[e]) {
+            if (!(a.fail[e] & 1u)) {
                 uint2 p = a.sorted[e];
                 uint64_t L = a.off[p.x + 1] - a.off[p.x];
                 ++cnt;

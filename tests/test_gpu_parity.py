@@ -151,14 +151,19 @@ def test_query_matches_oracle(gpu, n_genomes, k, nbits, h):
     for thr in (1.0, 0.0, 0.3, 0.5, 0.75, 0.999, 1.5, -1.0, float("nan")):
         st = check_query(gt, ot, reads, thr, path=0)
         assert st.path == 0
-    st = check_query(gt, ot, reads, 1.0, path=1)                   # bucketed: screen + records + L2-sliced verify
-    assert st.path == 1
-    os.environ["PFQ_RECORD_GB"] = "0"                              # bucketed without probe records (re-hash per slice)
-    try:
-        st = check_query(gt, ot, reads, 1.0, path=1)
-        assert st.path == 1
-    finally:
-        del os.environ["PFQ_RECORD_GB"]
+    st = check_query(gt, ot, reads, 1.0, path=1)                   # bucketed: screen + records + LDS-tile certificates
+    assert st.path == 1 and st.tile_mode == 1
+    for env, val, tile in (("PFQ_TILE_GB", "0", 1),                # no room for probe buckets: every pair takes the fallback
+                           ("PFQ_TILE", "0", 0),                   # record-driven L2-sliced verify only
+                           ("PFQ_RECORD_GB", "0", 0)):             # no probe records: re-hash per slice
+        os.environ[env] = val
+        try:
+            st = check_query(gt, ot, reads, 1.0, path=1)
+            assert st.path == 1 and st.tile_mode == tile
+            if env == "PFQ_TILE_GB":
+                assert 0 < st.n_fallback_pairs <= st.n_candidates and st.n_fallback_pairs >= 0.9 * st.n_candidates
+        finally:
+            del os.environ[env]
     gt.close()
 
 
