@@ -149,9 +149,11 @@ int pfq_set_path(pfq_tree *tree, int path);
  * launched on.  begin: record around the kernels of the next (up to max_calls) query calls; end: synchronise and sum. */
 typedef struct pfq_profile {
     uint64_t calls;
-    double classify_ms; /* k_classify (screen frontier + inline certificates) */
+    double classify_ms; /* k_classify (pre-screen, frontier, probe records or inline certificates) */
     double bucket_ms;   /* bucket scan + scatter */
-    double verify_ms;   /* k_verify (L2-sliced certificates) */
+    double bin_ms;      /* k_tile_plan + k_tile_bin (probes binned by leaf chunk and filter tile) */
+    double test_ms;     /* k_tile_test (tiles tested out of LDS) */
+    double verify_ms;   /* k_verify_rec / k_verify (L2-sliced certificates; only the fallback pairs in tile mode) */
     double finalize_ms; /* k_finalize */
 } pfq_profile;
 int pfq_profile_begin(pfq_tree *tree, uint32_t max_calls);

@@ -44,8 +44,8 @@ class Stats(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("calls", C.c_uint64), ("classify_ms", C.c_double), ("bucket_ms", C.c_double),
-                ("verify_ms", C.c_double), ("finalize_ms", C.c_double)]
+    _fields_ = [("calls", C.c_uint64), ("classify_ms", C.c_double), ("bucket_ms", C.c_double), ("bin_ms", C.c_double),
+                ("test_ms", C.c_double), ("verify_ms", C.c_double), ("finalize_ms", C.c_double)]
 
 
 WANT_HITS = 1

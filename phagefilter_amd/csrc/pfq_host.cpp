@@ -114,7 +114,7 @@ struct pfq_tree {
     hipStream_t last_stream = nullptr;
     int force_path = -1;
     // ---- profiling (HIP events on the launch stream)
-    std::vector<hipEvent_t> prof_ev;  // 5 events per recorded call
+    std::vector<hipEvent_t> prof_ev;  // PROF_EV events per recorded call
     size_t prof_cap = 0, prof_used = 0;
     std::vector<uint8_t> prof_bucketed;
     uint32_t last_path = 0, last_slices = 1;
@@ -409,6 +409,7 @@ int ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads) {
     return PFQ_OK;
 }
 
+constexpr int PROF_EV = 7;  // start, classify, bucket, plan+bin, test, verify, finalize
 constexpr uint64_t BUCKET_MIN_READS = 1ull << 18;  // below this the bucketed pass cannot amortise warming the L2 slices
 constexpr uint64_t SLICE_TARGET_BYTES = 2560ull << 10;
 
@@ -462,7 +463,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             const bool counts_mode = !(threshold >= 1.0f);  // theta >= 1: need >= n for every read with k-mers
             hipEvent_t *ev = nullptr;
             if (t.prof_used < t.prof_cap) {
-                ev = &t.prof_ev[5 * t.prof_used];
+                ev = &t.prof_ev[PROF_EV * t.prof_used];
                 t.prof_bucketed[t.prof_used] = bucketed;
                 ++t.prof_used;
             }
@@ -532,7 +533,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 // LDS-tile certificates: every probe binned by (leaf chunk, 128 KiB filter tile), tiles tested out of LDS;
                 // k_verify_rec then only sees the pairs that could not be binned
                 const uint32_t n_tiles = (uint32_t)((t.n_words * 64 + (1ull << pfq::TILE_LOG2) - 1) >> pfq::TILE_LOG2);
-                bool tile_mode = recs && n_tiles <= pfq::MAX_TILES;
+                bool tile_mode = recs && n_tiles < pfq::MAX_TILES;  // the last LDS counter is the dummy bin of idle lanes
                 if (const char *e = getenv("PFQ_TILE")) tile_mode = tile_mode && atoi(e) != 0;
                 uint64_t tile_budget = 64ull << 30;
                 if (const char *e = getenv("PFQ_TILE_GB")) tile_budget = strtoull(e, nullptr, 10) << 30;
@@ -582,15 +583,21 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         if (const char *e = getenv("PFQ_TEST_BLOCKS")) test_blocks = std::max(1, atoi(e));
                         pfq::launch_tile_plan(ta, st);
                         pfq::launch_tile_bin(ta, bin_blocks, st);
+                        if (ev) HIP_TRY(hipEventRecord(ev[3], st));
                         pfq::launch_tile_test(ta, test_blocks, st);
+                        if (ev) HIP_TRY(hipEventRecord(ev[4], st));
                         v.only_flagged = 1;
                         v.n_flagged = ta.n_flagged;
                         v.flag_list = t.d_flag_list.p;
                         t.last_tile_mode = 1;
                     }
                 }
+                if (ev && !t.last_tile_mode) {
+                    HIP_TRY(hipEventRecord(ev[3], st));
+                    HIP_TRY(hipEventRecord(ev[4], st));
+                }
                 pfq::launch_verify(v, vblocks, vthreads, st);
-                if (ev) HIP_TRY(hipEventRecord(ev[3], st));
+                if (ev) HIP_TRY(hipEventRecord(ev[5], st));
                 pfq::FinalizeArgs f{};
                 f.hp = t.hp;
                 f.off = d_off;
@@ -605,7 +612,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 f.hit_cursor = t.d_cursors.p;
                 f.stats = t.d_stats.p;
                 pfq::launch_finalize(f, st);
-                if (ev) HIP_TRY(hipEventRecord(ev[4], st));
+                if (ev) HIP_TRY(hipEventRecord(ev[6], st));
             } else {
                 pfq::launch_classify(a, false, counts_mode, blocks, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
@@ -1122,7 +1129,7 @@ int pfq_profile_begin(pfq_tree *tree, uint32_t max_calls) {
     if (!tree) return fail(PFQ_ERR_ARG, "null argument");
     PFQ_TRY(use_device(tree->device));
     pfq_tree &t = *tree;
-    while (t.prof_ev.size() < 5 * (size_t)max_calls) {
+    while (t.prof_ev.size() < PROF_EV * (size_t)max_calls) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         t.prof_ev.push_back(e);
@@ -1139,7 +1146,7 @@ int pfq_profile_end(pfq_tree *tree, pfq_profile *out) {
     memset(out, 0, sizeof *out);
     HIP_TRY(hipStreamSynchronize(t.last_stream));
     for (size_t c = 0; c < t.prof_used; ++c) {
-        hipEvent_t *ev = &t.prof_ev[5 * c];
+        hipEvent_t *ev = &t.prof_ev[PROF_EV * c];
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
         out->classify_ms += ms;
@@ -1147,8 +1154,12 @@ int pfq_profile_end(pfq_tree *tree, pfq_profile *out) {
             HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2]));
             out->bucket_ms += ms;
             HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3]));
-            out->verify_ms += ms;
+            out->bin_ms += ms;
             HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4]));
+            out->test_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5]));
+            out->verify_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[5], ev[6]));
             out->finalize_ms += ms;
         }
     }

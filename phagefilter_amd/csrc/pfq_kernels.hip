@@ -689,8 +689,9 @@ void launch_tile_plan(const TileArgs &a, hipStream_t st) {
     if (a.n_leaves) hipLaunchKernelGGL(k_tile_plan, dim3(a.n_leaves), dim3(256), 0, st, a);
 }
 
-constexpr uint32_t BIN_WAVES = 8;       // pairs binned per round by one block
-constexpr uint32_t BIN_CAP = 128;       // LDS entries per tile and round (mean ~75 at 150 bp / 138 tiles)
+constexpr uint32_t BIN_WAVES = 8;       // pairs binned per round by one block (4 with 64-entry bins measured slower and spills more)
+constexpr uint32_t BIN_CAP = 128;       // LDS entries per tile and round (mean ~75 at 150 bp / 138 tiles, +6 sigma)
+constexpr uint32_t BIN_STRIDE = BIN_CAP + 1;  // odd stride: bins fill in step, so slot s of every tile would share a bank
 constexpr uint32_t NO_PAIR = 0xfffffffeu;
 __device__ __forceinline__ void flag_fallback(const TileArgs &a, uint32_t e) {
     if (!(atomicOr(&a.fail[e], 2u) & 2u)) {
@@ -706,14 +707,39 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t n_pairs = *a.n_pairs_ptr;
     const uint32_t d = (uint32_t)a.hp.nbits, dw = d - (uint32_t)a.hp.w64, k = a.hp.k, nh = a.hp.num_hashes;
-    // a block takes rounds of BIN_WAVES consecutive sorted pairs, one pair per wave; the pairs of a round that
-    // belong to the same chunk are binned together (normally all of them), chunk after chunk
+    // A block takes rounds of BIN_WAVES consecutive sorted pairs, one pair per wave; the pairs of a round that belong
+    // to the same chunk are binned together (normally all of them), chunk after chunk.  The round loop is software-
+    // pipelined: the next round's pair metadata is fetched while this round is binned, and this round's records
+    // are requested before the block-wide bookkeeping.
     const uint32_t n_rounds = (n_pairs + BIN_WAVES - 1) / BIN_WAVES;
+    auto fetch = [&](uint32_t rd, uint32_t &chunk, uint4 &m) {
+        const uint32_t e = rd * BIN_WAVES + wave;
+        const bool have = rd < n_rounds && e < n_pairs;
+        chunk = have ? a.pair_chunk[e] : NO_PAIR;
+        m = have ? a.meta[e] : make_uint4(0, 0, 0, 0);
+    };
+    uint32_t nxt_chunk;
+    uint4 nxt_meta;
+    fetch(blockIdx.x, nxt_chunk, nxt_meta);
+    uint32_t cached_id = NO_PAIR;
+    ChunkDesc dsc{};
     for (uint32_t rd = blockIdx.x; rd < n_rounds; rd += gridDim.x) {
         const uint32_t e = rd * BIN_WAVES + wave;
-        const bool have = e < n_pairs;
-        uint32_t my_chunk = have ? a.pair_chunk[e] : NO_PAIR;
-        if (have && my_chunk == 0xffffffffu) {  // chunk table full: fallback
+        uint32_t my_chunk = nxt_chunk;
+        const uint4 m = nxt_meta;
+        const uint64_t o0 = ((uint64_t)m.y << 32) | m.x, n = my_chunk == NO_PAIR ? 0 : (uint64_t)m.z - k + 1;
+        const uint4 *rp = a.recs + o0;
+        // this round's first three windows of records
+        uint4 rec0[3];
+        bool valid0[3];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const uint64_t q = 64u * w + lane;
+            valid0[w] = my_chunk != NO_PAIR && my_chunk != 0xffffffffu && q < n;
+            rec0[w] = valid0[w] ? rp[q] : make_uint4(0, 0, 0, 0);
+        }
+        fetch(rd + gridDim.x, nxt_chunk, nxt_meta);
+        if (my_chunk == 0xffffffffu) {  // chunk table full: fallback
             if (lane == 0) flag_fallback(a, e);
             my_chunk = NO_PAIR;
         }
@@ -729,64 +755,78 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
             for (uint32_t w = 0; w < BIN_WAVES; ++w)
                 if (s_wc[w] == cur) pending &= ~(1u << w);
             for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) cnt[t] = 0;
+            if (cur != cached_id) {  // block-uniform
+                dsc = a.chunks[cur];
+                cached_id = cur;
+            }
             __syncthreads();
-            const ChunkDesc dsc = a.chunks[cur];
             if (my_chunk == cur) {
                 if (dsc.cap == 0) {
                     if (lane == 0) flag_fallback(a, e);  // no bucket space for this chunk
                 } else {
-                    const uint4 m = a.meta[e];
-                    const uint64_t o0 = ((uint64_t)m.y << 32) | m.x, n = (uint64_t)m.z - k + 1;
                     const uint32_t local = (e - dsc.first) << TILE_LOG2;
-                    const uint4 *rp = a.recs + o0;
-                    bool spilled = false;
-                    for (uint64_t g0 = 0; g0 < n; g0 += 3 * WIN_KMERS) {  // three windows' records are loaded together
+                    for (uint64_t g0 = 0; g0 < n; g0 += 3 * WIN_KMERS) {
                         uint4 rec[3];
                         bool valid[3];
 #pragma unroll
                         for (int w = 0; w < 3; ++w) {
-                            const uint64_t q = g0 + 64u * w + lane;
-                            valid[w] = q < n;
-                            rec[w] = valid[w] ? rp[q] : make_uint4(0, 0, 0, 0);
+                            if (g0 == 0) {
+                                rec[w] = rec0[w];
+                                valid[w] = valid0[w];
+                            } else {
+                                const uint64_t q = g0 + 64u * w + lane;
+                                valid[w] = q < n;
+                                rec[w] = valid[w] ? rp[q] : make_uint4(0, 0, 0, 0);
+                            }
                         }
+                        // branch-free append (an overflowing bin keeps overwriting its last slot and is detected at
+                        // flush time, cnt > BIN_CAP, when the round's pairs are sent to the fallback); the three
+                        // windows advance together so three LDS atomics are in flight per step
+                        RecordIter rit[3];
 #pragma unroll
-                        for (int w = 0; w < 3; ++w) {
-                            RecordIter rit;
-                            rit.init(rec[w]);
-                            auto put = [&](uint32_t idx) {
-                                if (!valid[w]) return;
-                                const uint32_t tile = idx >> TILE_LOG2, ent = local | (idx & ((1u << TILE_LOG2) - 1u));
-                                const uint32_t slot = atomicAdd(&cnt[tile], 1u);
-                                if (slot < BIN_CAP) bins[tile * BIN_CAP + slot] = ent;
-                                else spilled = true;  // LDS bin full: this pair goes to the fallback
-                            };
-                            put(rit.i0);
-                            if (nh > 1) put(rit.g);
-                            if (nh > 2) put(rit.x);
-                            for (uint32_t i = 3; i < nh; ++i) put(rit.step(d, dw));
+                        for (int w = 0; w < 3; ++w) rit[w].init(rec[w]);
+                        auto put3 = [&](uint32_t i0, uint32_t i1, uint32_t i2) {
+                            const uint32_t ix[3] = {i0, i1, i2};
+                            uint32_t tile[3], slot[3];
+#pragma unroll
+                            for (int w = 0; w < 3; ++w) tile[w] = ix[w] >> TILE_LOG2;
+#pragma unroll
+                            for (int w = 0; w < 3; ++w) slot[w] = valid[w] ? atomicAdd(&cnt[tile[w]], 1u) : 0u;
+#pragma unroll
+                            for (int w = 0; w < 3; ++w)
+                                if (valid[w]) bins[tile[w] * BIN_STRIDE + min(slot[w], BIN_CAP - 1u)] = local | (ix[w] & ((1u << TILE_LOG2) - 1u));
+                        };
+                        put3(rit[0].i0, rit[1].i0, rit[2].i0);
+                        if (nh > 1) put3(rit[0].g, rit[1].g, rit[2].g);
+                        if (nh > 2) put3(rit[0].x, rit[1].x, rit[2].x);
+                        for (uint32_t i = 3; i < nh; ++i) {
+                            const uint32_t s0 = rit[0].step(d, dw), s1 = rit[1].step(d, dw), s2 = rit[2].step(d, dw);
+                            put3(s0, s1, s2);
                         }
                     }
-                    if (ballot64(spilled) && lane == 0) flag_fallback(a, e);
                 }
             }
             __syncthreads();
             // flush: every tile's bin goes to its (chunk, tile) bucket as one run; all reservations of the round
             // are made by one atomic instruction (one lane per tile), not tile after tile
             if (dsc.cap) {
+                bool over = false;
                 for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) {
+                    over = over || cnt[t] > BIN_CAP;
                     const uint32_t c = cnt[t] < BIN_CAP ? cnt[t] : BIN_CAP;
                     s_pos[t] = c ? atomicAdd(&a.gfill[(uint64_t)cur * a.n_tiles + t], c) : 0u;
                 }
-                __syncthreads();
+                if (__syncthreads_or(over) && my_chunk == cur && lane == 0) flag_fallback(a, e);  // an LDS bin overflowed
+
                 for (uint32_t t = wave; t < a.n_tiles; t += BIN_WAVES) {
                     const uint32_t c = cnt[t] < BIN_CAP ? cnt[t] : BIN_CAP;
                     if (c == 0) continue;
                     const uint32_t pos = s_pos[t];
                     uint32_t *dst = a.entries + dsc.base + (uint64_t)t * dsc.cap;
                     if (pos + c <= dsc.cap) {
-                        for (uint32_t i = lane; i < c; i += 64) dst[pos + i] = bins[t * BIN_CAP + i];
+                        for (uint32_t i = lane; i < c; i += 64) dst[pos + i] = bins[t * BIN_STRIDE + i];
                     } else {  // bucket full: the pairs whose probes are dropped take the fallback
-                        for (uint32_t i = lane; i < c; i += 64) flag_fallback(a, dsc.first + (bins[t * BIN_CAP + i] >> TILE_LOG2));
+                        for (uint32_t i = lane; i < c; i += 64) flag_fallback(a, dsc.first + (bins[t * BIN_STRIDE + i] >> TILE_LOG2));
                     }
                 }
             }
@@ -795,7 +835,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
     }
 }
 void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
-    size_t lds = (MAX_TILES + (size_t)a.n_tiles * BIN_CAP) * 4;
+    size_t lds = (MAX_TILES + (size_t)a.n_tiles * BIN_STRIDE) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
