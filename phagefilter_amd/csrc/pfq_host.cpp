@@ -98,7 +98,7 @@ struct pfq_tree {
     DevBuf<uint32_t> d_S, d_col_row, d_guard_off, d_guard_col;
     DevBuf<unsigned long long> d_counts;
     // ---- query scratch
-    DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit, [1] pair, [2] tile entries, [3] lo: chunks, hi: flagged pairs
+    DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit, [1] pair, [2] tile entries, [3] lo: chunks, hi: flagged pairs, [4] long reads
     DevBuf<uint32_t> d_entries, d_pair_chunk, d_leaf_chunk0, d_flag_list;  // LDS-tile certificates
     DevBuf<pfq::ChunkDesc> d_chunks;
     DevBuf<unsigned int> d_gfill;
@@ -106,7 +106,8 @@ struct pfq_tree {
     DevBuf<uint2> d_hit_pairs, d_pairs, d_sorted;
     DevBuf<uint32_t> d_bucket, d_fail;  // bucket: cnt[n], off[n+1], cur[n]
     DevBuf<unsigned int> d_queue;
-    DevBuf<uint8_t> d_allhit, d_seq;
+    DevBuf<uint8_t> d_allhit, d_seq, d_miss;
+    DevBuf<uint32_t> d_long;
     DevBuf<uint4> d_recs;  // probe records of the bucketed path (16 B per read byte)
     DevBuf<uint4> d_meta;  // resolved per-pair metadata for the record-driven verify
     DevBuf<uint64_t> d_off;
@@ -390,7 +391,7 @@ int build_layout(pfq_tree &t) {
 
 int ensure_scratch(pfq_tree &t, uint64_t n_reads, bool want_hits) {
     HIP_TRY(t.d_stats.ensure(pfq::ST_N));
-    HIP_TRY(t.d_cursors.ensure(4));
+    HIP_TRY(t.d_cursors.ensure(8));
     const uint64_t cap = 2 * n_reads + 1024;
     if (want_hits) {
         HIP_TRY(t.d_hit_pairs.ensure(cap));
@@ -424,16 +425,20 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     t.last_n_reads = n_reads;
     PFQ_TRY(ensure_scratch(t, n_reads, want_hits));
     const size_t nl = t.leaves.size();
-    bool bucketed = (t.force_path == 1) ||
-                    (t.force_path < 0 && threshold == 1.0f && n_reads >= BUCKET_MIN_READS);
-    if (!(threshold == 1.0f) || !t.guard_col.empty() || nl == 0) bucketed = false;
+    // bucketed path: threshold 1 (any certificate kernel), or 0 < threshold < 1 with probe records (per-k-mer miss bytes)
+    const bool thr_one = threshold == 1.0f, thr_frac = threshold > 0.0f && threshold < 1.0f;
+    uint64_t rec_budget = 64ull << 30;
+    if (const char *e = getenv("PFQ_RECORD_GB")) rec_budget = strtoull(e, nullptr, 10) << 30;
+    const bool recs_possible = total_bytes && t.nbits < (1ull << 30) && t.num_hashes <= 35 && total_bytes * 16 <= rec_budget;
+    bool bucketed = (t.force_path == 1) || (t.force_path < 0 && n_reads >= BUCKET_MIN_READS);
+    if (!(thr_one || (thr_frac && recs_possible)) || !t.guard_col.empty() || nl == 0) bucketed = false;
     if (bucketed) PFQ_TRY(ensure_bucket_scratch(t, n_reads));
     t.last_path = bucketed ? 1 : 0;
 
     uint64_t hit_cap = t.d_hit_pairs.n;
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIP_TRY(hipMemsetAsync(t.d_stats.p, 0, pfq::ST_N * 8, st));
-        HIP_TRY(hipMemsetAsync(t.d_cursors.p, 0, 32, st));
+        HIP_TRY(hipMemsetAsync(t.d_cursors.p, 0, 64, st));
         if (want_hits) {
             HIP_TRY(hipMemsetAsync(t.d_allhit.p, 0, n_reads + 1, st));
             if (attempt == 0 && nl)
@@ -461,6 +466,11 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             a.stats = t.d_stats.p;
             int blocks = (int)std::min<uint64_t>((n_reads + 3) / 4, 2048);
             const bool counts_mode = !(threshold >= 1.0f);  // theta >= 1: need >= n for every read with k-mers
+            if (counts_mode) {
+                HIP_TRY(t.d_long.ensure(n_reads + 1));
+                a.long_list = t.d_long.p;
+                a.n_long = reinterpret_cast<unsigned int *>(t.d_cursors.p + 4);
+            }
             hipEvent_t *ev = nullptr;
             if (t.prof_used < t.prof_cap) {
                 ev = &t.prof_ev[PROF_EV * t.prof_used];
@@ -481,15 +491,21 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 a.sub_log2 = sub_log2;
                 // probe records: hash survivors once instead of once per slice (needs d < 2^30, <= 35 hashes, room)
                 uint4 *recs = nullptr;
-                uint64_t rec_budget = 64ull << 30;
-                if (const char *e = getenv("PFQ_RECORD_GB")) rec_budget = strtoull(e, nullptr, 10) << 30;
-                if (total_bytes && t.nbits < (1ull << 30) && t.num_hashes <= 35 && total_bytes * 16 <= rec_budget) {
+                if (recs_possible) {
                     HIP_TRY(t.d_recs.ensure(total_bytes + 64));
                     HIP_TRY(t.d_meta.ensure(t.d_pairs.n));
                     recs = t.d_recs.p;
                 }
                 a.recs = recs;
                 a.rec_cap = recs ? t.d_recs.n : 0;
+                // thresholds < 1: slices report per-k-mer misses in a byte array indexed like the records
+                uint8_t *miss = nullptr;
+                if (counts_mode) {
+                    HIP_TRY(t.d_miss.ensure(total_bytes + 64));
+                    HIP_TRY(hipMemsetAsync(t.d_miss.p, 0, total_bytes + 64, st));
+                    miss = t.d_miss.p;
+                    a.one_pair_per_read = 1;
+                }
                 uint32_t n_slices = 1;
                 uint64_t slice_target = SLICE_TARGET_BYTES;
                 if (const char *e = getenv("PFQ_SLICE_KB")) slice_target = strtoull(e, nullptr, 10) << 10;
@@ -498,7 +514,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 HIP_TRY(hipMemsetAsync(cnt, 0, nb * 4, st));
                 HIP_TRY(hipMemsetAsync(t.d_fail.p, 0, t.d_fail.n * 4, st));
                 HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 128 * 4, st));
-                pfq::launch_classify(a, true, false, blocks, st);
+                pfq::launch_classify(a, true, counts_mode, blocks, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
                 pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nb, st);
                 pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, sub_log2, t.d_sorted.p,
@@ -515,6 +531,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 v.n_pairs_ptr = off + nb;
                 v.fail = t.d_fail.p;
                 v.recs = recs;
+                v.miss = miss;
                 v.meta = t.d_meta.p;
                 v.n_slices = n_slices;
                 uint64_t sb = (t.n_words * 64 + n_slices - 1) / n_slices;
@@ -533,7 +550,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 // LDS-tile certificates: every probe binned by (leaf chunk, 128 KiB filter tile), tiles tested out of LDS;
                 // k_verify_rec then only sees the pairs that could not be binned
                 const uint32_t n_tiles = (uint32_t)((t.n_words * 64 + (1ull << pfq::TILE_LOG2) - 1) >> pfq::TILE_LOG2);
-                bool tile_mode = recs && n_tiles < pfq::MAX_TILES;  // the last LDS counter is the dummy bin of idle lanes
+                bool tile_mode = recs && !counts_mode && n_tiles < pfq::MAX_TILES;
                 if (const char *e = getenv("PFQ_TILE")) tile_mode = tile_mode && atoi(e) != 0;
                 uint64_t tile_budget = 64ull << 30;
                 if (const char *e = getenv("PFQ_TILE_GB")) tile_budget = strtoull(e, nullptr, 10) << 30;
@@ -605,6 +622,8 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 f.bucket_off = off;
                 f.sub_log2 = sub_log2;
                 f.fail = t.d_fail.p;
+                f.miss = miss;
+                f.threshold = threshold;
                 f.n_leaves = (uint32_t)nl;
                 f.counts = t.d_counts.p;
                 f.hit_pairs = a.hit_pairs;

@@ -43,6 +43,10 @@ struct QueryArgs {
     uint32_t sub_log2;           // sub-buckets per leaf (so that no counter is a hot spot when leaves are few)
     uint4 *recs;                 // probe records, indexed by (read byte offset + k-mer position), or nullptr
     uint64_t rec_cap;            // entries in recs (reads whose records would not fit are certified inline)
+    uint32_t *long_list;         // thresholds < 1: reads of >= 256 k-mers, classified by a second launch (wider counters)
+    unsigned int *n_long;
+    uint32_t one_pair_per_read;  // thresholds < 1: the per-k-mer miss bytes are indexed by read, so only a read's
+                                 // first candidate is deferred (further candidates are certified inline)
 };
 
 struct VerifyArgs {
@@ -63,6 +67,8 @@ struct VerifyArgs {
     const unsigned int *n_flagged;  // number of such pairs (kernel returns at once when 0)
     const uint32_t *flag_list;      // their sorted-pair indices
     const uint4 *recs;           // probe records written by k_classify<DEFER> (nullptr: re-hash per slice)
+    uint8_t *miss;               // thresholds < 1: miss[read byte offset + k-mer] = 1 when a probed bit of that k-mer is 0
+                                 // (nullptr at threshold 1: any miss fails the pair)
     uint32_t chunk;
 };
 
@@ -73,6 +79,8 @@ struct FinalizeArgs {
     const uint32_t *bucket_off;  // [(n_leaves << sub_log2) + 1]
     uint32_t sub_log2;
     const uint32_t *fail;
+    const uint8_t *miss;         // thresholds < 1 (see VerifyArgs); nullptr at threshold 1
+    float threshold;
     uint32_t n_leaves;
     unsigned long long *counts;
     uint2 *hit_pairs;

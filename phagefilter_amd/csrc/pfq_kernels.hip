@@ -88,24 +88,24 @@ __device__ __forceinline__ uint32_t screen_all(BlockLds &lds, uint32_t wave, con
 }
 
 // ---- K3 (theta < 1): miss-counting frontier ---------------------------------------------------------------------------
-// A k-mer is a definite miss for a leaf if its first probed bit is 0.  Per-leaf miss counts are kept as
-// bit-sliced ("vertical") counters, one plane per register; a leaf leaves the frontier once misses > n - need.
-__device__ __forceinline__ void vc_add(uint32_t (&c)[NPLANES], uint32_t m) {
-#pragma unroll
-    for (uint32_t p = 0; p < NPLANES; ++p) {
-        uint32_t t = c[p] & m;
-        c[p] ^= m;
-        m = t;
-    }
+// A k-mer is a definite miss for a leaf if its first probed bit is 0.  Per-leaf miss counts are kept bit-sliced
+// ("vertical counters": plane p holds bit p of the count of each of the lane's 32 leaves).  Rows are consumed eight
+// at a time through a carry-save adder tree (7 CSAs = 14 three-input bit ops for eight rows, then one ripple add of
+// the "eights" into the upper planes) instead of one ripple-carry add per row; a leaf leaves the frontier once
+// misses > n - need.
+__device__ __forceinline__ void csa(uint32_t &hi, uint32_t &lo, uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t u = a ^ b;
+    hi = (a & b) | (u & c);
+    lo = u ^ c;
 }
-__device__ __forceinline__ uint32_t screen_counts(BlockLds &lds, uint32_t wave, const QueryArgs &a, const ReadCtx &rc,
-                                                  uint32_t colmask) {
+template <uint32_t P, uint32_t BATCH>  // counter planes (counts up to 2^P - 1); rows per lane in flight
+__device__ __forceinline__ uint32_t screen_counts_p(BlockLds &lds, uint32_t wave, const QueryArgs &a, const ReadCtx &rc,
+                                                    uint32_t colmask) {
     const uint32_t lane = lane_id(), rw = a.rw, slots = 64u >> a.rw_log2;
     const uint32_t word = lane & (rw - 1u), slot = lane >> a.rw_log2;
-    if (rc.n >= (1ull << NPLANES)) return colmask;  // counters too narrow: no screening, certify every leaf
-    uint32_t c[NPLANES];
+    uint32_t c[P];  // c[0] = ones, c[1] = twos, c[2] = fours, c[3..] = eights and up
 #pragma unroll
-    for (uint32_t p = 0; p < NPLANES; ++p) c[p] = 0;
+    for (uint32_t p = 0; p < P; ++p) c[p] = 0;
     uint32_t live = colmask;
     for (uint64_t base = 0; base < rc.n; base += WIN_KMERS) {
         uint32_t cnt = (uint32_t)((rc.n - base) < WIN_KMERS ? (rc.n - base) : WIN_KMERS);
@@ -113,40 +113,64 @@ __device__ __forceinline__ uint32_t screen_counts(BlockLds &lds, uint32_t wave, 
         uint64_t h1, h2;
         kmer_hashes(lds, wave, lane, cnt, lane < cnt, a.hp, h1, h2);
         uint32_t i0 = mod_nbits(h1, a.hp);
-        for (uint32_t t = 0; t < cnt; t += slots) {
-            uint32_t kk = t + slot;
-            bool valid = kk < cnt;
-            uint32_t r0 = (uint32_t)__shfl((int)i0, (int)(valid ? kk : 0u));
-            uint32_t v = valid ? a.S[(uint64_t)r0 * rw + word] : ~0u;
-            vc_add(c, ~v & colmask);
-        }
-        // total over the slots (ripple-carry add of vertical counters), then misses > maxmiss ?
-        uint32_t tot[NPLANES];
+        for (uint32_t t = 0; t < cnt; t += BATCH * slots) {
+            uint32_t m[BATCH];
 #pragma unroll
-        for (uint32_t p = 0; p < NPLANES; ++p) tot[p] = c[p];
-        for (uint32_t s = rw; s < 64u; s <<= 1) {
-            uint32_t carry = 0;
-#pragma unroll
-            for (uint32_t p = 0; p < NPLANES; ++p) {
-                uint32_t o = (uint32_t)__shfl_xor((int)tot[p], (int)s);
-                uint32_t x = tot[p] ^ o;
-                uint32_t sum = x ^ carry;
-                carry = (tot[p] & o) | (carry & x);
-                tot[p] = sum;
+            for (uint32_t j = 0; j < BATCH; ++j) {
+                const uint32_t kk = t + j * slots + slot;
+                const bool valid = kk < cnt;
+                const uint32_t r0 = (uint32_t)__shfl((int)i0, (int)(valid ? kk : 0u));
+                const uint32_t v = valid ? a.S[(uint64_t)r0 * rw + word] : ~0u;
+                m[j] = ~v & live;
             }
-        }
-        uint32_t gt = 0, eq = ~0u;
 #pragma unroll
-        for (int p = (int)NPLANES - 1; p >= 0; --p) {
-            uint32_t mb = ((rc.maxmiss >> p) & 1ull) ? ~0u : 0u;
-            gt |= eq & tot[p] & ~mb;
-            eq &= ~(tot[p] ^ mb);
+            for (uint32_t g = 0; g < BATCH; g += 8) {
+                uint32_t t2a, t2b, t4a, t4b, t8;
+                csa(t2a, c[0], c[0], m[g + 0], m[g + 1]);
+                csa(t2b, c[0], c[0], m[g + 2], m[g + 3]);
+                csa(t4a, c[1], c[1], t2a, t2b);
+                csa(t2a, c[0], c[0], m[g + 4], m[g + 5]);
+                csa(t2b, c[0], c[0], m[g + 6], m[g + 7]);
+                csa(t4b, c[1], c[1], t2a, t2b);
+                csa(t8, c[2], c[2], t4a, t4b);
+#pragma unroll
+                for (uint32_t p = 3; p < P; ++p) {  // ripple the eights upwards
+                    const uint32_t carry = c[p] & t8;
+                    c[p] ^= t8;
+                    t8 = carry;
+                }
+            }
+            // total over the slots (ripple-carry add of vertical counters), then misses > maxmiss ?
+            uint32_t tot[P];
+#pragma unroll
+            for (uint32_t p = 0; p < P; ++p) tot[p] = c[p];
+            for (uint32_t s = rw; s < 64u; s <<= 1) {
+                uint32_t carry = 0;
+#pragma unroll
+                for (uint32_t p = 0; p < P; ++p) {
+                    uint32_t o = (uint32_t)__shfl_xor((int)tot[p], (int)s);
+                    uint32_t x = tot[p] ^ o;
+                    uint32_t sum = x ^ carry;
+                    carry = (tot[p] & o) | (carry & x);
+                    tot[p] = sum;
+                }
+            }
+            uint32_t gt = 0, eq = ~0u;
+#pragma unroll
+            for (int p = (int)P - 1; p >= 0; --p) {
+                uint32_t mb = ((rc.maxmiss >> p) & 1ull) ? ~0u : 0u;
+                gt |= eq & tot[p] & ~mb;
+                eq &= ~(tot[p] ^ mb);
+            }
+            live &= ~gt;
+            if (ballot64(live != 0) == 0) return 0;
         }
-        live = colmask & ~gt;
-        if (ballot64(live != 0) == 0) return 0;
     }
     return live;
 }
+// Reads of fewer than 256 k-mers take eight planes; longer ones are queued for a second launch of the kernel built
+// with NPLANES planes, so that the common case keeps its registers (and its occupancy).
+constexpr uint64_t SHORT_KMERS = 256;
 
 // ---- dense pre-screen (theta == 1) -------------------------------------------------------------------------------------
 // Most reads of a metagenome hit nothing, and the AND-frontier needs only their first four k-mers: a wave screens
@@ -251,11 +275,163 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
     return survive;
 }
 
+// ---- dense miss-counting screen (theta < 1) -------------------------------------------------------------------------
+// The per-read frontier above is a chain of dependent round trips (stage, hash, gather, count) per read and wave.
+// Here a wave screens 64/lpr consecutive reads at once, lpr = rw/4 lanes per read: lane (j, q) hashes k-mer
+// pos+q of read j and owns dwords 4q..4q+3 (128 leaf columns) of every row of that read, so the vertical counters
+// never cross lanes; each pass issues lpr row gathers of 16 bytes per lane before any is consumed.  Needs
+// 16 <= rw <= 64 and reads of fewer than SHORT_KMERS k-mers; other reads are returned in `irregular` for the
+// per-read path.  On return live_out[j*rw + w] holds the frontier words of read j and `survive` the reads with a
+// non-empty frontier.
+__device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const uint8_t *comp, uint32_t *live_out,
+                                             const QueryArgs &a, uint64_t r0, uint32_t n_in_group, uint32_t &survive,
+                                             uint32_t &irregular, uint64_t &lane_len) {
+    constexpr uint32_t P = 8;
+    const uint32_t lane = lane_id(), k = a.hp.k, rw = a.rw;
+    const uint32_t lpr_log2 = a.rw_log2 - 2u, lpr = 1u << lpr_log2, rpw = 64u >> lpr_log2;
+    const uint32_t j = lane >> lpr_log2, q = lane & (lpr - 1u);
+    uint64_t o0 = 0, L = 0;
+    if (j < n_in_group) {
+        o0 = a.off[r0 + j];
+        L = a.off[r0 + j + 1] - o0;
+    }
+    lane_len = (q == 0) ? L : 0;
+    const uint64_t n64 = (L >= k) ? (L - k + 1) : 0;
+    const uint64_t need = need_kmers(a.threshold, n64);
+    const bool in_group = j < n_in_group;
+    const bool regular = in_group && n64 >= 1 && n64 < SHORT_KMERS && need >= 1 && need <= n64;
+    const uint32_t n = regular ? (uint32_t)n64 : 0u, maxmiss = regular ? (uint32_t)(n64 - need) : 0u;
+    irregular = 0;
+    {
+        uint64_t b = ballot64(in_group && !regular && q == 0);
+        while (b) {
+            const int l = __ffsll((unsigned long long)b) - 1;
+            b &= b - 1;
+            irregular |= 1u << ((uint32_t)l >> lpr_log2);
+        }
+    }
+    uint32_t live[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t w = q * 4u + u;
+        const uint32_t cm = (w * 32u < a.n_leaves) ? ((a.n_leaves - w * 32u >= 32u) ? ~0u : ((1u << (a.n_leaves - w * 32u)) - 1u)) : 0u;
+        live[u] = regular ? cm : 0u;
+    }
+    uint32_t c[P][4];
+#pragma unroll
+    for (uint32_t p = 0; p < P; ++p)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[p][u] = 0;
+    uint8_t *fwd = reinterpret_cast<uint8_t *>(fw), *rcb = reinterpret_cast<uint8_t *>(rw_);
+    const uint32_t stride = (DENSE_READS / rpw) * MINI_BYTES;  // bytes of LDS per read and direction (rpw <= 16)
+    const uint32_t base = j * stride + WIN_PAD;
+    bool alive = regular;  // my read still has a live leaf
+    for (uint32_t pos = 0;; pos += lpr) {
+        const bool active = alive && pos < n;
+        if (ballot64(active) == 0) break;
+        const uint32_t nk = active ? (n - pos < lpr ? n - pos : lpr) : 0u;
+        const uint32_t W = nk ? nk + k - 1u : 0u;  // bytes staged for my read: <= lpr + KMAX - 1
+        __builtin_amdgcn_wave_barrier();
+        // six bytes per lane and batch; the loads are unconditional (clamped address) so that none waits for another
+        const uint8_t *src = a.seq + (active ? o0 + pos : 0ull);
+        for (uint32_t i0 = 0; i0 < k + lpr - 1u; i0 += 6u * lpr) {
+            uint8_t b[6];
+#pragma unroll
+            for (uint32_t u = 0; u < 6; ++u) {
+                const uint32_t idx = i0 + lpr * u + q;
+                b[u] = src[idx < W ? idx : 0u];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 6; ++u) {
+                const uint32_t idx = i0 + lpr * u + q;
+                if (idx < W) {
+                    fwd[base + idx] = b[u];
+                    rcb[base + (W - 1u - idx)] = comp[b[u]];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool valid = q < nk;
+        uint64_t h1, h2;
+        kmer_hashes_at(fw, rw_, base + q, base + (W - q - k), valid, a.hp, h1, h2);
+        const uint32_t i0v = mod_nbits(h1, a.hp);
+        for (uint32_t t0 = 0; t0 < lpr; t0 += 8u) {
+            uint4 m[8];
+            // unconditional loads: lanes without a row read the first 16 bytes of S (one hot line) and discard them
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t t = t0 + u;
+                const bool pv = t < nk;
+                const uint32_t x = (uint32_t)__shfl((int)i0v, (int)((j << lpr_log2) + (pv ? t : 0u)));
+                m[u] = *reinterpret_cast<const uint4 *>(a.S + (pv ? ((uint64_t)x << a.rw_log2) + q * 4u : 0ull));
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const bool pv = t0 + u < nk;
+                m[u].x = pv ? ~m[u].x & live[0] : 0u;
+                m[u].y = pv ? ~m[u].y & live[1] : 0u;
+                m[u].z = pv ? ~m[u].z & live[2] : 0u;
+                m[u].w = pv ? ~m[u].w & live[3] : 0u;
+            }
+#define PFQ_CSA_WORD(F, W_)                                                   \
+    {                                                                         \
+        uint32_t t2a, t2b, t4a, t4b, t8;                                      \
+        csa(t2a, c[0][W_], c[0][W_], m[0].F, m[1].F);                         \
+        csa(t2b, c[0][W_], c[0][W_], m[2].F, m[3].F);                         \
+        csa(t4a, c[1][W_], c[1][W_], t2a, t2b);                               \
+        csa(t2a, c[0][W_], c[0][W_], m[4].F, m[5].F);                         \
+        csa(t2b, c[0][W_], c[0][W_], m[6].F, m[7].F);                         \
+        csa(t4b, c[1][W_], c[1][W_], t2a, t2b);                               \
+        csa(t8, c[2][W_], c[2][W_], t4a, t4b);                                \
+        _Pragma("unroll") for (uint32_t p = 3; p < P; ++p) {                  \
+            const uint32_t carry = c[p][W_] & t8;                             \
+            c[p][W_] ^= t8;                                                   \
+            t8 = carry;                                                       \
+        }                                                                     \
+    }
+            PFQ_CSA_WORD(x, 0)
+            PFQ_CSA_WORD(y, 1)
+            PFQ_CSA_WORD(z, 2)
+            PFQ_CSA_WORD(w, 3)
+#undef PFQ_CSA_WORD
+        }
+        // misses > maxmiss ?  (per lane: maxmiss belongs to the lane's read)
+        uint32_t any = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t gt = 0, eq = ~0u;
+#pragma unroll
+            for (int p = (int)P - 1; p >= 0; --p) {
+                const uint32_t mbit = ((maxmiss >> p) & 1u) ? ~0u : 0u;
+                gt |= eq & c[p][u] & ~mbit;
+                eq &= ~(c[p][u] ^ mbit);
+            }
+            live[u] &= ~gt;
+            any |= live[u];
+        }
+        for (uint32_t sft = 1; sft < lpr; sft <<= 1) any |= (uint32_t)__shfl_xor((int)any, (int)sft);
+        alive = alive && any != 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) live_out[j * rw + q * 4u + u] = live[u];
+    __builtin_amdgcn_wave_barrier();
+    survive = 0;
+    {
+        uint64_t b = ballot64(alive && q == 0);
+        while (b) {
+            const int l = __ffsll((unsigned long long)b) - 1;
+            b &= b - 1;
+            survive |= 1u << ((uint32_t)l >> lpr_log2);
+        }
+    }
+}
+
 // ---- the classification kernel ---------------------------------------------------------------------------------------
-template <bool DEFER, bool COUNTS>
+template <bool DEFER, bool COUNTS, bool LONG = false>
 __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
     __shared__ BlockLds lds;
-    __shared__ DenseLds<DEFER && !COUNTS> dlds;
+    __shared__ DenseLds<DEFER ? !LONG : (COUNTS && !LONG)> dlds;
     fill_complement(lds.comp);
     __syncthreads();
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -271,12 +447,16 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
     unsigned long long pair_base = 0;
     uint32_t pair_used = PAIR_CHUNK;
 
-    auto process_read = [&](uint64_t r) {
+    auto process_read = [&](uint64_t r, const uint32_t *pre) {  // pre: frontier words from the dense counting screen
         const uint64_t o0 = a.off[r], L = a.off[r + 1] - o0;
         ReadCtx rc;
         rc.read = a.seq + o0;
         rc.n = (L >= a.hp.k) ? (L - a.hp.k + 1) : 0;  // get_kmers, file_parser.rs:135-138
         rc.need = need_kmers(a.threshold, rc.n);       // query.rs:48
+        if (COUNTS && !LONG && !pre && rc.n >= SHORT_KMERS && rc.need != 0 && rc.need <= rc.n) {
+            if (lane == 0) a.long_list[atomicAdd(a.n_long, 1u)] = (uint32_t)r;  // second launch (LONG)
+            return;
+        }
         st_bytes += L;
         if (rc.need == 0) {  // 0 >= 0 at every node: the read reaches and counts at every leaf
             ++st_all;
@@ -291,7 +471,12 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
         bool prepared = false, have_w0 = false;
         uint64_t w0_h1 = 0, w0_h2 = 0;  // hashes of the first window when the AND-frontier computed them
         uint32_t live;
-        if (COUNTS) live = screen_counts(lds, wave, a, rc, colmask);
+        if (COUNTS) {
+            if (pre) live = pre[word] & colmask;
+            else if (!LONG) live = screen_counts_p<8, 16>(lds, wave, a, rc, colmask);
+            else if (rc.n < (1ull << NPLANES)) live = screen_counts_p<NPLANES, 8>(lds, wave, a, rc, colmask);
+            else live = colmask;  // counters too narrow: no screening, certify every leaf
+        }
         else if (rc.maxmiss == 0) { live = screen_all(lds, wave, a, rc, colmask, w0_h1, w0_h2); have_w0 = true; }
         else live = colmask;
 
@@ -304,7 +489,7 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             uint32_t col = (uint32_t)src * 32u + bit;
             if ((int)lane == src) live &= ~(1u << bit);
             ++st_cand;
-            if (DEFER && (!a.recs || o0 + rc.n <= a.rec_cap)) {
+            if (DEFER && (!a.recs || o0 + rc.n <= a.rec_cap) && !(a.one_pair_per_read && prepared)) {
                 if (pair_used == PAIR_CHUNK) {  // wave-uniform
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(a.pair_cursor, (unsigned long long)PAIR_CHUNK);
@@ -369,11 +554,37 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             while (survive) {
                 const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
                 survive &= survive - 1u;
-                process_read(r0 + jj);
+                process_read(r0 + jj, nullptr);
             }
         }
+    } else if (COUNTS && !LONG && a.rw >= 16u) {
+        // thresholds < 1: groups of 64/(rw/4) consecutive reads through the dense counting screen
+        const uint32_t rpw = 256u >> a.rw_log2;
+        const uint64_t n_groups = (a.n_reads + rpw - 1) / rpw;
+        for (uint64_t g = gw; g < n_groups; g += nw) {
+            const uint64_t r0 = g * rpw;
+            const uint32_t cnt = (uint32_t)(a.n_reads - r0 < rpw ? a.n_reads - r0 : rpw);
+            uint64_t lane_len;
+            uint32_t survive, irregular;
+            dense_counts(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, r0, cnt, survive, irregular,
+                         lane_len);
+            if (!(((survive | irregular) >> (lane >> (a.rw_log2 - 2u))) & 1u)) dense_bytes += lane_len;
+            while (survive) {
+                const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
+                survive &= survive - 1u;
+                process_read(r0 + jj, dlds.live[wave] + jj * rw);
+            }
+            while (irregular) {
+                const uint32_t jj = (uint32_t)__ffs((int)irregular) - 1u;
+                irregular &= irregular - 1u;
+                process_read(r0 + jj, nullptr);
+            }
+        }
+    } else if (LONG) {
+        const uint64_t n_long = *a.n_long;
+        for (uint64_t i = gw; i < n_long; i += nw) process_read(a.long_list[i], nullptr);
     } else {
-        for (uint64_t r = gw; r < a.n_reads; r += nw) process_read(r);
+        for (uint64_t r = gw; r < a.n_reads; r += nw) process_read(r, nullptr);
     }
     if (DEFER && pair_used < PAIR_CHUNK)
         for (uint32_t i = pair_used + lane; i < PAIR_CHUNK; i += 64) a.pairs[pair_base + i] = make_uint2(0xffffffffu, 0xffffffffu);
@@ -394,11 +605,15 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
 void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int blocks, hipStream_t st) {
     dim3 g(blocks), b(256);
     if (defer) {
-        if (counts_mode) hipLaunchKernelGGL((k_classify<true, true>), g, b, 0, st, a);
-        else hipLaunchKernelGGL((k_classify<true, false>), g, b, 0, st, a);
+        if (counts_mode) {
+            hipLaunchKernelGGL((k_classify<true, true>), g, b, 0, st, a);
+            hipLaunchKernelGGL((k_classify<true, true, true>), g, b, 0, st, a);
+        } else hipLaunchKernelGGL((k_classify<true, false>), g, b, 0, st, a);
     } else {
-        if (counts_mode) hipLaunchKernelGGL((k_classify<false, true>), g, b, 0, st, a);
-        else hipLaunchKernelGGL((k_classify<false, false>), g, b, 0, st, a);
+        if (counts_mode) {
+            hipLaunchKernelGGL((k_classify<false, true>), g, b, 0, st, a);
+            hipLaunchKernelGGL((k_classify<false, true, true>), g, b, 0, st, a);
+        } else hipLaunchKernelGGL((k_classify<false, false>), g, b, 0, st, a);
     }
 }
 
@@ -585,7 +800,7 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
                     // probes 0..2 of the three windows: nine independent gathers, then the walk two probes at a
                     // time per window (six gathers in flight); uses come after the loads of a batch
                     RecordIter rit[3];
-                    uint32_t ok = 1;
+                    uint32_t okw[3] = {1u, 1u, 1u};  // per window: AND of this lane's probed bits in the slice
                     {
                         uint32_t ix[9], vv[9];
 #pragma unroll
@@ -601,7 +816,7 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
                             vv[u] = in ? bm[ix[u] >> 5] : ~0u;
                         }
 #pragma unroll
-                        for (int u = 0; u < 9; ++u) ok &= vv[u] >> (ix[u] & 31u);
+                        for (int u = 0; u < 9; ++u) okw[u / 3] &= vv[u] >> (ix[u] & 31u);
                     }
                     for (uint32_t i = 3; i < nh; i += 2) {
                         const bool second = i + 1 < nh;  // wave-uniform
@@ -617,9 +832,15 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
                             vv[u] = in ? bm[ix[u] >> 5] : ~0u;
                         }
 #pragma unroll
-                        for (int u = 0; u < 6; ++u) ok &= vv[u] >> (ix[u] & 31u);
+                        for (int u = 0; u < 6; ++u) okw[u / 2] &= vv[u] >> (ix[u] & 31u);
                     }
-                    miss = miss || !(ok & 1u);
+                    if (a.miss) {  // thresholds < 1: record which k-mers are not contained (idempotent byte stores)
+#pragma unroll
+                        for (int w = 0; w < 3; ++w)
+                            if (valid[w] && !(okw[w] & 1u)) a.miss[o0 + g0 + 64u * w + lane] = 1;
+                    } else {
+                        miss = miss || !(okw[0] & okw[1] & okw[2] & 1u);
+                    }
                 }
                 if (ballot64(miss) && lane == 0) atomicOr(&a.fail[bcast_u32(idx_cur, j)], 1u);
             }
@@ -919,11 +1140,19 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
         __syncthreads();
         unsigned long long cnt = 0, bytes = 0;
         for (uint32_t e = a.bucket_off[c << a.sub_log2] + threadIdx.x; e < a.bucket_off[(c + 1) << a.sub_log2]; e += blockDim.x) {
-            if (!(a.fail[e] & 1u)) {
-                uint2 p = a.sorted[e];
-                uint64_t L = a.off[p.x + 1] - a.off[p.x];
+            uint2 p = a.sorted[e];
+            const uint64_t o0 = a.off[p.x], L = a.off[p.x + 1] - o0, n = L - a.hp.k + 1;
+            uint64_t need = n;
+            bool pass;
+            if (a.miss) {  // thresholds < 1: contained k-mers = n - missing ones; query_passes (query.rs:38-49)
+                uint64_t missing = 0;
+                for (uint64_t q = 0; q < n; ++q) missing += a.miss[o0 + q];
+                need = need_kmers(a.threshold, n);
+                pass = n - missing >= need;
+            } else pass = !(a.fail[e] & 1u);
+            if (pass) {
                 ++cnt;
-                bytes += (L - a.hp.k + 1) * a.hp.num_hashes * 32ull;
+                bytes += need * a.hp.num_hashes * 32ull;
                 if (a.hit_pairs) {
                     unsigned long long pos = atomicAdd(a.hit_cursor, 1ull);
                     if (pos < a.hit_cap) a.hit_pairs[pos] = p;

@@ -139,6 +139,24 @@ TREES = [(1, 21, 30011, 5), (2, 21, 30011, 10), (3, 11, 20000, 3), (8, 21, 10000
          (70, 16, 200003, 10), (130, 21, 262144, 10)]
 
 
+@pytest.mark.parametrize("n_genomes", [300, 600, 1100])
+def test_wide_trees_all_thresholds(gpu, n_genomes):
+    """Trees of 16, 32 and 64 row words: the dense screens (AND-frontier at theta = 1, miss counters below) run with
+    4, 8 and 16 lanes per read; reads of >= 256 k-mers take the wide-counter launch."""
+    k, nbits, h = 21, 120011, 4
+    genomes = [rand_dna(int(RNG.integers(200, 500))) for _ in range(n_genomes)]
+    genomes[5] = genomes[4]
+    genomes[7] = genomes[6][:150] + genomes[7][150:]
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    gt = gpu_tree(genomes, ids, k, nbits, h)
+    reads = make_reads(genomes, 400, 150, 150, k) + make_reads(genomes, 12, 6, 420, k) + make_reads(genomes, 20, 5, k + 3, k)
+    for thr in (1.0, 0.3, 0.7, 0.95, 0.0):
+        for path in (0, 1):
+            st = check_query(gt, ot, reads, thr, path=path)
+            assert st.path == (path if 0.0 < thr <= 1.0 else 0)
+    gt.close()
+
+
 @pytest.mark.parametrize("n_genomes,k,nbits,h", TREES)
 def test_query_matches_oracle(gpu, n_genomes, k, nbits, h):
     genomes = [rand_dna(int(RNG.integers(300, 1500))) for _ in range(n_genomes)]
@@ -151,6 +169,11 @@ def test_query_matches_oracle(gpu, n_genomes, k, nbits, h):
     for thr in (1.0, 0.0, 0.3, 0.5, 0.75, 0.999, 1.5, -1.0, float("nan")):
         st = check_query(gt, ot, reads, thr, path=0)
         assert st.path == 0
+    for thr in (0.3, 0.5, 0.75, 0.999):                            # bucketed at thresholds < 1: per-k-mer miss bytes
+        st = check_query(gt, ot, reads, thr, path=1)
+        assert st.path == 1 and st.tile_mode == 0
+    for thr in (0.0, 1.5, float("nan")):                           # nothing to certify: stays on the direct kernel
+        assert check_query(gt, ot, reads, thr, path=1).path == 0
     st = check_query(gt, ot, reads, 1.0, path=1)                   # bucketed: screen + records + LDS-tile certificates
     assert st.path == 1 and st.tile_mode == 1
     for env, val, tile in (("PFQ_TILE_GB", "0", 1),                # no room for probe buckets: every pair takes the fallback
