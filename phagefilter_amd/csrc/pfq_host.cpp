@@ -369,7 +369,7 @@ int build_layout(pfq_tree &t) {
         return PFQ_OK;
     }
     const size_t s_words = (size_t)t.n_words * 64 * t.rw;
-    HIP_TRY(t.d_S.ensure(s_words));
+    HIP_TRY(t.d_S.ensure(s_words + t.rw));  // + the all-ones row
     HIP_TRY(t.d_col_row.ensure(t.col_row.size()));
     HIP_TRY(t.d_guard_off.ensure(t.guard_off.size() + t.n_cols));  // guard lists are indexed by column; pad for guard columns
     HIP_TRY(t.d_guard_col.ensure(std::max<size_t>(1, t.guard_col.size())));
@@ -381,7 +381,8 @@ int build_layout(pfq_tree &t) {
     std::vector<unsigned long long> h(nl);
     for (size_t i = 0; i < nl; ++i) h[i] = t.nodes[t.leaves[i]].mapped_reads;
     HIP_TRY(hipMemcpy(t.d_counts.p, h.data(), nl * 8, hipMemcpyHostToDevice));
-    if (t.rw * 32 > t.n_cols || true) HIP_TRY(hipMemsetAsync(t.d_S.p, 0, s_words * 4, nullptr));
+    HIP_TRY(hipMemsetAsync(t.d_S.p, 0, s_words * 4, nullptr));
+    HIP_TRY(hipMemsetAsync(t.d_S.p + s_words, 0xff, t.rw * 4, nullptr));
     pfq::launch_transpose(t.d_bits.p, t.n_words, t.d_col_row.p, t.n_cols, t.d_S.p, t.rw, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -452,6 +453,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             a.n_reads = n_reads;
             a.threshold = threshold;
             a.S = t.d_S.p;
+            a.ones_row = (uint32_t)(t.n_words * 64);
             a.rw = t.rw;
             a.rw_log2 = t.rw_log2;
             a.n_leaves = (uint32_t)nl;

@@ -3,7 +3,7 @@
 //
 //   bits   u64[n_filters][n_words]   node-major filters in the reference's own bit order (BitVec<usize,Lsb0>,
 //                                    bloom_filter.rs:86): bit idx = word idx>>6, mask 1<<(idx&63).
-//   S      u32[n_words*64][rw]       "sliced" matrix: row = bit index, column = leaf (left-to-right DFS order)
+//   S      u32[n_words*64 + 1][rw]   "sliced" matrix (last row: all ones, the target of predicated-off gathers): row = bit index, column = leaf (left-to-right DFS order)
 //                                    followed by guard columns (ancestors whose ⊇ check failed).  One 128-B line
 //                                    answers the same probe for 1024 leaves.
 #pragma once
@@ -24,6 +24,7 @@ struct QueryArgs {
     float threshold;
     // sliced matrix
     const uint32_t *S;
+    uint32_t ones_row;           // index of the all-ones row stored behind the last bit row of S
     uint32_t rw, rw_log2;        // row words (power of two <= 64)
     uint32_t n_leaves, n_cols;   // leaf columns, leaf+guard columns
     const uint32_t *guard_off;   // [n_leaves+1] CSR into guard_col (may be all zeros)

@@ -310,18 +310,21 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
             irregular |= 1u << ((uint32_t)l >> lpr_log2);
         }
     }
-    uint32_t live[4];
+    // cm: leaf columns of my four dwords; dead: leaves whose miss count exceeded maxmiss.  The counters start at
+    // 2^P - 1 - maxmiss, so "misses > maxmiss" is the carry out of the top plane: no comparison is needed, and rows
+    // need no masking either (counters of dead leaves and of padding columns may wrap, they stay dead).
+    uint32_t cm[4], dead[4];
+    const uint32_t bias = regular ? ((1u << P) - 1u - maxmiss) : 0u;
+    uint32_t c[P][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const uint32_t w = q * 4u + u;
-        const uint32_t cm = (w * 32u < a.n_leaves) ? ((a.n_leaves - w * 32u >= 32u) ? ~0u : ((1u << (a.n_leaves - w * 32u)) - 1u)) : 0u;
-        live[u] = regular ? cm : 0u;
+        cm[u] = (w * 32u < a.n_leaves) ? ((a.n_leaves - w * 32u >= 32u) ? ~0u : ((1u << (a.n_leaves - w * 32u)) - 1u)) : 0u;
+        if (!regular) cm[u] = 0u;
+        dead[u] = 0u;
+#pragma unroll
+        for (uint32_t p = 0; p < P; ++p) c[p][u] = ((bias >> p) & 1u) ? ~0u : 0u;
     }
-    uint32_t c[P][4];
-#pragma unroll
-    for (uint32_t p = 0; p < P; ++p)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) c[p][u] = 0;
     uint8_t *fwd = reinterpret_cast<uint8_t *>(fw), *rcb = reinterpret_cast<uint8_t *>(rw_);
     const uint32_t stride = (DENSE_READS / rpw) * MINI_BYTES;  // bytes of LDS per read and direction (rpw <= 16)
     const uint32_t base = j * stride + WIN_PAD;
@@ -354,33 +357,28 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
         const bool valid = q < nk;
         uint64_t h1, h2;
         kmer_hashes_at(fw, rw_, base + q, base + (W - q - k), valid, a.hp, h1, h2);
-        const uint32_t i0v = mod_nbits(h1, a.hp);
+        // row indices of the wave go through LDS (live_out is free until the end): a lane fetches the eight of its
+        // read with two 16-byte reads; k-mers that do not exist point at the all-ones row behind S (no miss)
+        live_out[lane] = valid ? mod_nbits(h1, a.hp) : a.ones_row;
+        __builtin_amdgcn_wave_barrier();
         for (uint32_t t0 = 0; t0 < lpr; t0 += 8u) {
+            const uint4 xa = *reinterpret_cast<const uint4 *>(live_out + (j << lpr_log2) + t0);
+            const uint4 xb = *reinterpret_cast<const uint4 *>(live_out + (j << lpr_log2) + t0 + 4u);
+            const uint32_t xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
             uint4 m[8];
-            // unconditional loads: lanes without a row read the first 16 bytes of S (one hot line) and discard them
 #pragma unroll
             for (uint32_t u = 0; u < 8; ++u) {
-                const uint32_t t = t0 + u;
-                const bool pv = t < nk;
-                const uint32_t x = (uint32_t)__shfl((int)i0v, (int)((j << lpr_log2) + (pv ? t : 0u)));
-                m[u] = *reinterpret_cast<const uint4 *>(a.S + (pv ? ((uint64_t)x << a.rw_log2) + q * 4u : 0ull));
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) {
-                const bool pv = t0 + u < nk;
-                m[u].x = pv ? ~m[u].x & live[0] : 0u;
-                m[u].y = pv ? ~m[u].y & live[1] : 0u;
-                m[u].z = pv ? ~m[u].z & live[2] : 0u;
-                m[u].w = pv ? ~m[u].w & live[3] : 0u;
+                const uint32_t x = (t0 + u < lpr) ? xs[u] : a.ones_row;  // lpr == 4: the upper four belong to the next read
+                m[u] = *reinterpret_cast<const uint4 *>(a.S + ((uint64_t)x << a.rw_log2) + q * 4u);
             }
 #define PFQ_CSA_WORD(F, W_)                                                   \
     {                                                                         \
         uint32_t t2a, t2b, t4a, t4b, t8;                                      \
-        csa(t2a, c[0][W_], c[0][W_], m[0].F, m[1].F);                         \
-        csa(t2b, c[0][W_], c[0][W_], m[2].F, m[3].F);                         \
+        csa(t2a, c[0][W_], c[0][W_], ~m[0].F, ~m[1].F);                       \
+        csa(t2b, c[0][W_], c[0][W_], ~m[2].F, ~m[3].F);                       \
         csa(t4a, c[1][W_], c[1][W_], t2a, t2b);                               \
-        csa(t2a, c[0][W_], c[0][W_], m[4].F, m[5].F);                         \
-        csa(t2b, c[0][W_], c[0][W_], m[6].F, m[7].F);                         \
+        csa(t2a, c[0][W_], c[0][W_], ~m[4].F, ~m[5].F);                       \
+        csa(t2b, c[0][W_], c[0][W_], ~m[6].F, ~m[7].F);                       \
         csa(t4b, c[1][W_], c[1][W_], t2a, t2b);                               \
         csa(t8, c[2][W_], c[2][W_], t4a, t4b);                                \
         _Pragma("unroll") for (uint32_t p = 3; p < P; ++p) {                  \
@@ -388,6 +386,7 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
             c[p][W_] ^= t8;                                                   \
             t8 = carry;                                                       \
         }                                                                     \
+        dead[W_] |= t8;                                                       \
     }
             PFQ_CSA_WORD(x, 0)
             PFQ_CSA_WORD(y, 1)
@@ -395,23 +394,13 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
             PFQ_CSA_WORD(w, 3)
 #undef PFQ_CSA_WORD
         }
-        // misses > maxmiss ?  (per lane: maxmiss belongs to the lane's read)
-        uint32_t any = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            uint32_t gt = 0, eq = ~0u;
-#pragma unroll
-            for (int p = (int)P - 1; p >= 0; --p) {
-                const uint32_t mbit = ((maxmiss >> p) & 1u) ? ~0u : 0u;
-                gt |= eq & c[p][u] & ~mbit;
-                eq &= ~(c[p][u] ^ mbit);
-            }
-            live[u] &= ~gt;
-            any |= live[u];
-        }
+        uint32_t any = (cm[0] & ~dead[0]) | (cm[1] & ~dead[1]) | (cm[2] & ~dead[2]) | (cm[3] & ~dead[3]);
         for (uint32_t sft = 1; sft < lpr; sft <<= 1) any |= (uint32_t)__shfl_xor((int)any, (int)sft);
         alive = alive && any != 0;
     }
+    uint32_t live[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) live[u] = cm[u] & ~dead[u];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < 4; ++u) live_out[j * rw + q * 4u + u] = live[u];
