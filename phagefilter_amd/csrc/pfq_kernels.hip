@@ -1134,8 +1134,18 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
             uint64_t need = n;
             bool pass;
             if (a.miss) {  // thresholds < 1: contained k-mers = n - missing ones; query_passes (query.rs:38-49)
+                // miss bytes are 0/1: sum them as popcounts of the aligned 8-byte words covering [o0, o0+n)
+                const uint64_t lo = o0 & ~7ull, end = o0 + n;
+                const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(a.miss + lo);
+                const uint32_t nw = (uint32_t)(((end + 7ull) & ~7ull) - lo) >> 3;
                 uint64_t missing = 0;
-                for (uint64_t q = 0; q < n; ++q) missing += a.miss[o0 + q];
+#pragma unroll 4
+                for (uint32_t w = 0; w < nw; ++w) {
+                    unsigned long long v = mw[w];
+                    if (w == 0) v &= ~0ull << (8u * (uint32_t)(o0 & 7ull));
+                    if (w == nw - 1u && (end & 7ull)) v &= (1ull << (8u * (uint32_t)(end & 7ull))) - 1ull;
+                    missing += (uint64_t)__popcll(v);
+                }
                 need = need_kmers(a.threshold, n);
                 pass = n - missing >= need;
             } else pass = !(a.fail[e] & 1u);
