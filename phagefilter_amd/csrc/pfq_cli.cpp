@@ -7,22 +7,29 @@
 // NEG_FILTERING.*.  `build` / `add` (tree construction) are out of scope; `build-balanced` makes the synthetic
 // balanced tree of SURVEY §8d from a genome directory so the query path can be exercised end to end.
 #include <dirent.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <set>
 #include <thread>
 #include <string>
+#include <unordered_map>
+#include <string_view>
 #include <vector>
 
 #include "../../include/pfq.h"
@@ -106,24 +113,27 @@ Fmt detect_format(const std::string &path, FmtOverride ov) {  // file_parser.rs:
     return format_from_extension(path);
 }
 
-// Line reader over a (possibly gzip-compressed) file.  Lines are handed out as views into the read buffer
-// (no per-line allocation); a line that straddles a buffer refill is assembled in `carry`.
-struct LineReader {
+// ---------------------------------------------------------------------------------------------------------------
+// line sources: a (possibly gzip-compressed) stream, or a range of a memory-mapped plain file
+// ---------------------------------------------------------------------------------------------------------------
+// Lines are handed out as views (no per-line allocation); with GzLines a line that straddles a buffer refill is
+// assembled in `carry`.  A view stays valid until the next call.
+struct GzLines {
     gzFile f = nullptr;
     std::vector<char> buf;
     std::string carry;
     size_t pos = 0, len = 0;
     bool eof = false;
-    explicit LineReader(const std::string &path) : buf(4 << 20) {
+    explicit GzLines(const std::string &path) : buf(4 << 20) {
         f = gzopen(path.c_str(), "rb");
         if (!f) die("Failed to open '" + path + "': " + strerror(errno));
         gzbuffer(f, 1 << 20);
     }
-    ~LineReader() {
+    GzLines(const GzLines &) = delete;
+    ~GzLines() {
         if (f) gzclose(f);
     }
-    // One line without its '\n' as [p, p+n); false at end of file with nothing read.  The view stays valid until
-    // the next call.
+    // One line without its '\n' as [p, p+n); false at end of file with nothing read.
     bool next(const char *&p, size_t &n) {
         bool use_carry = false;
         while (true) {
@@ -157,17 +167,32 @@ struct LineReader {
             pos = len;
         }
     }
+    bool drained() const { return eof && pos == len; }
+    uint64_t tell() const { return 0; }  // positions are only used with MemLines
+};
+struct MemLines {
+    const char *base, *cur, *end;
+    MemLines(const char *b, uint64_t from, uint64_t to) : base(b), cur(b + from), end(b + to) {}
+    bool next(const char *&p, size_t &n) {
+        if (cur == end) return false;
+        const char *nl = (const char *)memchr(cur, '\n', (size_t)(end - cur));
+        p = cur;
+        if (nl) {
+            n = (size_t)(nl - cur);
+            cur = nl + 1;
+        } else {
+            n = (size_t)(end - cur);
+            cur = end;
+        }
+        return true;
+    }
+    bool drained() const { return false; }
+    uint64_t tell() const { return (uint64_t)(cur - base); }
 };
 
 inline size_t trimmed_len(const char *p, size_t n) {  // str::trim_end
     while (n && isspace((unsigned char)p[n - 1])) --n;
     return n;
-}
-std::string id_of(const char *h, size_t n) {  // bio Record::id(): first whitespace-delimited token after the marker
-    n = trimmed_len(h, n);
-    size_t i = 1;
-    while (i < n && !isspace((unsigned char)h[i])) ++i;
-    return std::string(h + 1, i > 1 ? i - 1 : 0);
 }
 
 // One block of reads in the layout the C ABI takes (concatenated bases + n+1 offsets); ids and qualities are kept
@@ -175,46 +200,92 @@ std::string id_of(const char *h, size_t n) {  // bio Record::id(): first whitesp
 struct Batch {
     std::vector<uint8_t> seq;
     std::vector<uint64_t> off{0};
-    std::vector<std::string> ids;
-    std::vector<char> qual;           // concatenated qualities (same offsets as seq) when has_qual
+    std::vector<char> id_bytes;       // concatenated ids (bio Record::id()) when kept
+    std::vector<uint64_t> id_off{0};
+    std::vector<char> qual;           // concatenated qualities when kept (bio does not require |qual| == |seq|)
+    std::vector<uint64_t> qual_off{0};
     std::vector<uint8_t> has_qual;    // per read
     size_t n() const { return off.size() - 1; }
     void clear() {
         seq.clear();
         off.assign(1, 0);
-        ids.clear();
+        id_bytes.clear();
+        id_off.assign(1, 0);
         qual.clear();
+        qual_off.assign(1, 0);
         has_qual.clear();
+    }
+    std::string_view quality(size_t r) const { return std::string_view(qual.data() + qual_off[r], qual_off[r + 1] - qual_off[r]); }
+    std::string_view id(size_t r) const { return std::string_view(id_bytes.data() + id_off[r], id_off[r + 1] - id_off[r]); }
+    // Record::id(): header[1..].trim_end() up to the first separator — any whitespace in bio's FASTA reader
+    // (`splitn(2, char::is_whitespace)`), a blank only in its FASTQ reader (`splitn(2, ' ')`)
+    void push_id(const char *h, size_t n, bool fastq) {
+        n = trimmed_len(h, n);
+        size_t i = 1;
+        while (i < n && !(fastq ? h[i] == ' ' : isspace((unsigned char)h[i]))) ++i;
+        if (i > 1) id_bytes.insert(id_bytes.end(), h + 1, h + i);
+        id_off.push_back(id_bytes.size());
+    }
+    // reads [r0, r1) of `o` appended to this batch
+    void append(const Batch &o, size_t r0, size_t r1, bool keep) {
+        const uint64_t s0 = o.off[r0], s1 = o.off[r1], base = seq.size();
+        seq.insert(seq.end(), o.seq.begin() + s0, o.seq.begin() + s1);
+        for (size_t r = r0 + 1; r <= r1; ++r) off.push_back(base + (o.off[r] - s0));
+        if (!keep) return;
+        const uint64_t i0 = o.id_off[r0], i1 = o.id_off[r1], ib = id_bytes.size();
+        id_bytes.insert(id_bytes.end(), o.id_bytes.begin() + i0, o.id_bytes.begin() + i1);
+        for (size_t r = r0 + 1; r <= r1; ++r) id_off.push_back(ib + (o.id_off[r] - i0));
+        const uint64_t q0 = o.qual_off[r0], q1 = o.qual_off[r1], qb = qual.size();
+        qual.insert(qual.end(), o.qual.begin() + q0, o.qual.begin() + q1);
+        for (size_t r = r0 + 1; r <= r1; ++r) qual_off.push_back(qb + (o.qual_off[r] - q0));
+        has_qual.insert(has_qual.end(), o.has_qual.begin() + r0, o.has_qual.begin() + r1);
     }
 };
 
-// bio::io::fasta / fastq record iteration (multi-line sequences; FASTQ qualities read until they cover the
-// sequence), appending straight into a Batch.
-struct RecordReader {
-    LineReader lr;
+// bio 2.2.0 `io::fasta::Reader::read` / `io::fastq::Reader::read` as the reference consumes them through
+// `.records()` + `unwrap()` (file_parser.rs:191-224; no `Record::check()`), appending straight into a Batch:
+//   FASTA: header line must start with '>'; every following line up to the next '>' line is sequence, trimmed at
+//          the end;
+//   FASTQ: header line must start with '@'; lines up to the first '+' line are sequence (trimmed, counted); then
+//          the SAME NUMBER of lines is read as quality (trimmed); an empty quality is `IncompleteRecord`.  Lengths
+//          of sequence and quality are not compared (that is `check()`, which the reference never calls).
+// bio is a crates.io dependency that is not vendored in the reference: multi-line and malformed-record behaviour is
+// restated from its published source, parity unpinned; the reference's own parser tests (file_parser.rs:410-604)
+// only hold ordinary four-line records, which every reading of the rules agrees on.  Malformed input is reported through `err` (the caller decides when
+// it becomes fatal: a speculative parse from a guessed record boundary must not kill the process).
+template <class Src>
+struct RecordParser {
+    Src &lr;
     Fmt fmt;
-    std::string pending;  // a header line already consumed while finishing the previous FASTA record
+    std::string header, pending;  // pending: a header line already consumed while finishing the previous FASTA record
     bool have_pending = false;
-    RecordReader(const std::string &path, Fmt f) : lr(path), fmt(f) {}
-    bool next(Batch &b, bool keep) {
+    uint64_t pending_pos = 0;     // where that line starts (MemLines)
+    std::string err;
+    RecordParser(Src &s, Fmt f) : lr(s), fmt(f) {}
+    // Position at which the next record starts (MemLines only).
+    uint64_t next_record_pos() const { return have_pending ? pending_pos : lr.tell(); }
+    // 1: a record was appended; 0: clean end of input; -1: malformed (message in err)
+    int next(Batch &b, bool keep) {
         const char *p;
         size_t n;
-        std::string header;
         if (have_pending) {
             header.swap(pending);
             have_pending = false;
         } else {
-            if (!lr.next(p, n)) return false;
-            if (n == 0 && lr.eof && lr.pos == lr.len) return false;
+            if (!lr.next(p, n)) return 0;
+            if (n == 0 && lr.drained()) return 0;
             header.assign(p, n);
         }
         const size_t seq0 = b.seq.size();
         if (fmt == Fmt::Fasta) {
-            if (header.empty() || header[0] != '>') die("FASTA: Expected > at record start.");
-            while (lr.next(p, n)) {
+            if (header.empty() || header[0] != '>') { err = "FASTA: Expected > at record start."; return -1; }
+            while (true) {
+                const uint64_t at = lr.tell();
+                if (!lr.next(p, n)) break;
                 if (n && p[0] == '>') {
                     pending.assign(p, n);
                     have_pending = true;
+                    pending_pos = at;
                     break;
                 }
                 n = trimmed_len(p, n);
@@ -222,68 +293,389 @@ struct RecordReader {
             }
             b.off.push_back(b.seq.size());
             if (keep) {
-                b.ids.push_back(id_of(header.data(), header.size()));
+                b.push_id(header.data(), header.size(), false);
+                b.qual_off.push_back(b.qual.size());
                 b.has_qual.push_back(0);
-                b.qual.resize(b.seq.size(), 0);
             }
-            return true;
+            return 1;
         }
-        if (header.empty() || header[0] != '@') die("FASTQ: Expected @ at record start.");
-        bool plus = false;
+        if (header.empty() || header[0] != '@') { err = "FASTQ: Expected @ at record start."; return -1; }
+        size_t lines_read = 0;
         while (lr.next(p, n)) {
-            if (n && p[0] == '+') {
-                plus = true;
-                break;
-            }
+            if (n && p[0] == '+') break;
             n = trimmed_len(p, n);
             b.seq.insert(b.seq.end(), p, p + n);
+            ++lines_read;
         }
-        if (!plus) die("FASTQ: Incomplete record (missing '+' line).");
-        const size_t slen = b.seq.size() - seq0;
+        const size_t q0 = b.qual.size();
         size_t qlen = 0;
-        if (keep) b.qual.resize(seq0, 0);
-        while (qlen < slen) {
-            if (!lr.next(p, n)) die("FASTQ: Incomplete record (quality shorter than sequence).");
+        for (size_t i = 0; i < lines_read; ++i) {
+            if (!lr.next(p, n)) break;  // read_line at end of file: nothing appended
             n = trimmed_len(p, n);
             if (keep) b.qual.insert(b.qual.end(), p, p + n);
             qlen += n;
         }
-        if (qlen != slen) die("FASTQ: Unequal length of sequence and quality.");
+        if (qlen == 0) {
+            b.seq.resize(seq0);
+            b.qual.resize(q0);
+            err = "FASTQ: Incomplete record.";
+            return -1;
+        }
         b.off.push_back(b.seq.size());
         if (keep) {
-            b.ids.push_back(id_of(header.data(), header.size()));
+            b.push_id(header.data(), header.size(), true);
+            b.qual_off.push_back(b.qual.size());
             b.has_qual.push_back(1);
         }
-        return true;
+        return 1;
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
 // ReadQueue (file_parser.rs:227-301): files consumed from the back of the list, records streamed across files.
+//
+// At 10^8 reads/s the text is the end-to-end limiter, so parsing is spread over `threads` workers:
+//   * a plain file is memory-mapped and cut into chunks; every chunk is parsed on its own from the first record
+//     start at or after its nominal begin to the first record start at or after its nominal end.  A FASTA record
+//     start is any line beginning with '>' (exact); a FASTQ record start is guessed ('@' line followed by two
+//     well-formed records) and then PROVEN by the consumer: chunk i+1 is accepted only if it starts exactly where
+//     chunk i ended, which by induction from offset 0 makes every accepted start a true one.  A chunk that fails the
+//     check is re-parsed from the proven position, so the result never depends on the guess;
+//   * a gzip file is inflated and parsed by one worker as a stream of segments; several files run concurrently.
+// Segments are consumed strictly in input order, so blocks, ids and outputs are those of a sequential reader.
+// ---------------------------------------------------------------------------------------------------------------
+struct Segment {
+    Batch b;
+    std::vector<char> raw;                // plain chunks: the bytes of the file the records were parsed from
+    uint64_t start_pos = 0, end_pos = 0;  // plain chunks: first record start, start of the record after the last one
+    std::string err;                      // malformed input met after the records in b
+    bool last = true;                     // gzip streams: more segments of this task follow when false
+};
+struct MappedFile {  // (plain files are read with pread into reused buffers: first-touch page faults of a mapping
+    uint64_t size = 0;   //  cost more than the copy, and serialise the workers)
+    int fd = -1;
+    bool gz = false;
+};
+// bytes [lo, hi) of a file held in memory; p is the address byte 0 of the file would have
+struct FileView {
+    const char *p;
+    uint64_t lo, hi;
+};
+struct Task {
+    int file = 0;
+    uint64_t lo = 0, hi = 0;  // nominal byte range of a plain chunk
+    bool stream = false;      // gzip file: one streaming task
+    std::deque<Segment *> out;
+    bool taken = false;
+};
+
 struct ReadQueue {
-    std::vector<std::string> files;
+    std::vector<std::string> files;   // consumption order (the reference pops from the back of its list)
+    std::vector<Fmt> fmts;
+    std::vector<MappedFile> maps;
+    std::vector<Task> tasks;
     FmtOverride ov;
-    RecordReader *cur = nullptr;
-    ReadQueue(const std::string &path, FmtOverride o) : files(get_file_names(path)), ov(o) {}
-    ~ReadQueue() { delete cur; }
-    Fmt peek_format() const { return files.empty() ? Fmt::Fasta : detect_format(files.back(), ov); }
-    bool next(Batch &b, bool keep) {
-        while (true) {
-            if (!cur) {
-                if (files.empty()) return false;
-                std::string p = files.back();
-                files.pop_back();
-                cur = new RecordReader(p, detect_format(p, ov));
+    bool keep = false;
+    unsigned n_threads = 1;
+    uint64_t chunk_bytes = 32ull << 20, seg_reads = 1u << 18;
+    size_t lookahead = 8;
+
+    std::mutex mu;
+    std::condition_variable cv_work, cv_out;
+    size_t next_task = 0, consume_task = 0;
+    bool stop = false, started = false;
+    std::vector<std::thread> workers;
+
+    std::vector<Segment *> pool;  // consumed segments, handed back to the workers with their (warm) buffers
+    Segment *cur = nullptr;  // segment being consumed
+    size_t cur_read = 0;
+    bool have_proven = false;
+    uint64_t proven_pos = 0;  // plain files: where the next record of the current file provably starts
+
+    ReadQueue(const std::string &path, FmtOverride o) : ov(o) {
+        files = get_file_names(path);
+        std::reverse(files.begin(), files.end());
+        for (auto &f : files) fmts.push_back(detect_format(f, ov));
+    }
+    ~ReadQueue() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        cv_out.notify_all();
+        for (auto &t : workers) t.join();
+        delete cur;
+        for (auto *s : pool) delete s;
+        for (auto &t : tasks)
+            for (auto *s : t.out) delete s;
+        for (auto &m : maps)
+            if (m.fd >= 0) close(m.fd);
+    }
+    Fmt peek_format() const { return files.empty() ? Fmt::Fasta : fmts.front(); }
+
+    void start(bool keep_ids, unsigned threads) {
+        keep = keep_ids;
+        n_threads = std::max(1u, threads);
+        if (!keep) {  // counts only: a segment is one device call, which wants >= 2^18 reads (bucketed path)
+            chunk_bytes = 128ull << 20;
+            seg_reads = 1u << 19;
+        }
+        if (const char *e = getenv("PFQ_INGEST_CHUNK_BYTES")) chunk_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        if (const char *e = getenv("PFQ_INGEST_SEGMENT_READS")) seg_reads = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        lookahead = (size_t)n_threads + 2;
+        for (size_t i = 0; i < files.size(); ++i) {
+            MappedFile m;
+            m.fd = open(files[i].c_str(), O_RDONLY);
+            if (m.fd < 0) die("Failed to open '" + files[i] + "': " + strerror(errno));
+            struct stat st;
+            if (fstat(m.fd, &st) != 0) die("cannot stat '" + files[i] + "'");
+            m.size = (uint64_t)st.st_size;
+            unsigned char magic[2] = {0, 0};
+            m.gz = pread(m.fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+            if (!m.gz) posix_fadvise(m.fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+            maps.push_back(m);
+            if (m.gz) {
+                Task t;
+                t.file = (int)i;
+                t.stream = true;
+                tasks.push_back(std::move(t));
+            } else {
+                for (uint64_t lo = 0; lo < std::max<uint64_t>(m.size, 1); lo += chunk_bytes) {
+                    Task t;
+                    t.file = (int)i;
+                    t.lo = lo;
+                    t.hi = std::min(m.size, lo + chunk_bytes);
+                    tasks.push_back(std::move(t));
+                }
             }
-            if (cur->next(b, keep)) return true;
-            delete cur;
-            cur = nullptr;
+        }
+        started = true;
+        for (unsigned i = 0; i < n_threads; ++i) workers.emplace_back([this] { work(); });
+    }
+
+    // ---- chunk parsing ----------------------------------------------------------------------------------------
+    // First record start at or after `from` (a line start) inside the view, or v.hi when there is none.
+    uint64_t find_record_start(const FileView &v, Fmt fmt, uint64_t from) const {
+        if (from == 0) return 0;
+        uint64_t pos = from;
+        if (v.p[pos - 1] != '\n') {  // not a line start: move to the next one
+            const char *nl = (const char *)memchr(v.p + pos, '\n', v.hi - pos);
+            if (!nl) return v.hi;
+            pos = (uint64_t)(nl - v.p) + 1;
+        }
+        const char marker = fmt == Fmt::Fasta ? '>' : '@';
+        while (pos < v.hi) {
+            if (v.p[pos] == marker) {
+                if (fmt == Fmt::Fasta) return pos;
+                // FASTQ: '@' also starts quality lines; take the candidate if two records parse from it
+                MemLines ml(v.p, pos, v.hi);
+                RecordParser<MemLines> rp(ml, fmt);
+                Batch scratch;
+                int ok = rp.next(scratch, false);
+                if (ok == 1) ok = rp.next(scratch, false);
+                if (ok >= 0) return pos;  // (0: the file ends after the first record)
+            }
+            const char *nl = (const char *)memchr(v.p + pos, '\n', v.hi - pos);
+            if (!nl) return v.hi;
+            pos = (uint64_t)(nl - v.p) + 1;
+        }
+        return v.hi;
+    }
+    // Records starting in [start, nominal_end), parsed out of the view; returns whether the parser ran into the end of
+    // the view (the caller reads more of the file and parses again unless the view ends where the file does).
+    bool parse_view(const FileView &v, Fmt fmt, uint64_t start, uint64_t nominal_end, Segment &s) const {
+        s.start_pos = start;
+        if (nominal_end > start) {  // one allocation per buffer instead of a doubling series
+            const uint64_t span = nominal_end - start;
+            s.b.seq.reserve(span / (fmt == Fmt::Fastq ? 2 : 1) + 4096);
+            s.b.off.reserve(span / 64 + 16);
+        }
+        MemLines ml(v.p, std::min(start, v.hi), v.hi);
+        RecordParser<MemLines> rp(ml, fmt);
+        while (rp.next_record_pos() < nominal_end) {
+            int rc = rp.next(s.b, keep);
+            if (rc == 0) break;
+            if (rc < 0) {
+                s.err = rp.err;
+                break;
+            }
+        }
+        s.end_pos = rp.next_record_pos();
+        return ml.cur == ml.end;
+    }
+    // Chunk [lo, hi) of a plain file: records from the first record start at or after `lo` (or from `forced_start` when
+    // the consumer knows it) up to the first record start at or after `hi`.
+    void parse_chunk(const MappedFile &m, Fmt fmt, uint64_t lo, uint64_t hi, bool forced, uint64_t forced_start, Segment &s) {
+        if (!m.size) return;
+        const uint64_t want_lo = forced ? std::min(forced_start, m.size) : (lo ? lo - 1 : 0);
+        for (uint64_t extra = 1ull << 20;; extra *= 8) {
+            const uint64_t r_hi = std::min(m.size, std::max(hi, want_lo) + extra);
+            s.raw.resize((size_t)(r_hi - want_lo));
+            for (uint64_t got = 0; got < r_hi - want_lo;) {
+                ssize_t n = pread(m.fd, s.raw.data() + got, (size_t)(r_hi - want_lo - got), (off_t)(want_lo + got));
+                if (n < 0) die(std::string("read error: ") + strerror(errno));
+                if (n == 0) die("input file shrank while it was being read");
+                got += (uint64_t)n;
+            }
+            const FileView v{(const char *)((uintptr_t)s.raw.data() - (uintptr_t)want_lo), want_lo, r_hi};
+            s.b.clear();
+            s.err.clear();
+            const uint64_t t0 = now_ns();
+            const uint64_t start = forced ? forced_start : find_record_start(v, fmt, lo);
+            const uint64_t t1 = now_ns();
+            const bool hit_end = parse_view(v, fmt, start, hi, s);
+            ns_find += t1 - t0;
+            ns_parse += now_ns() - t1;
+            if (!hit_end || r_hi == m.size) return;  // otherwise the last record may be cut: read further
         }
     }
+    Segment *fresh_segment() {
+        Segment *s = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!pool.empty()) {
+                s = pool.back();
+                pool.pop_back();
+            }
+        }
+        if (!s) return new Segment;
+        s->b.clear();
+        s->start_pos = s->end_pos = 0;
+        s->err.clear();
+        s->last = true;
+        return s;
+    }
+    void recycle(Segment *s) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (pool.size() < lookahead + 4) pool.push_back(s);
+        else delete s;
+    }
+    void push(Task &t, Segment *s) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            t.out.push_back(s);
+        }
+        cv_out.notify_all();
+    }
+    void work() {
+        while (true) {
+            size_t ti;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || (next_task < tasks.size() && next_task < consume_task + lookahead); });
+                if (stop) return;
+                ti = next_task++;
+            }
+            Task &t = tasks[ti];
+            const MappedFile &m = maps[t.file];
+            const Fmt fmt = fmts[t.file];
+            if (!t.stream) {
+                Segment *s = fresh_segment();
+                parse_chunk(m, fmt, t.lo, t.hi, false, 0, *s);
+                push(t, s);
+                continue;
+            }
+            GzLines gl(files[t.file]);
+            RecordParser<GzLines> rp(gl, fmt);
+            while (true) {
+                Segment *s = fresh_segment();
+                int rc = 1;
+                while (s->b.n() < seg_reads && (rc = rp.next(s->b, keep)) == 1) {}
+                if (rc < 0) s->err = rp.err;
+                s->last = rc != 1;
+                {
+                    std::unique_lock<std::mutex> lk(mu);  // bounded: at most four segments of a stream wait
+                    cv_work.wait(lk, [&] { return stop || t.out.size() < 4; });
+                    if (stop) {
+                        delete s;
+                        return;
+                    }
+                    t.out.push_back(s);
+                }
+                cv_out.notify_all();
+                if (rc != 1) break;
+            }
+        }
+    }
+
+    // ---- ordered consumption ----------------------------------------------------------------------------------
+    // Next segment in input order (validated), or nullptr at the end of the input.
+    Segment *next_segment() {
+        while (consume_task < tasks.size()) {
+            Task &t = tasks[consume_task];
+            Segment *s;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_out.wait(lk, [&] { return !t.out.empty(); });
+                s = t.out.front();
+                t.out.pop_front();
+            }
+            cv_work.notify_all();
+            const bool task_done = s->last;
+            if (!t.stream) {
+                const MappedFile &m = maps[t.file];
+                const uint64_t expect = t.lo == 0 ? 0 : proven_pos;
+                if (m.size && s->start_pos != expect) {  // guessed boundary was wrong (or a record spans chunks): redo
+                    parse_chunk(m, fmts[t.file], t.lo, t.hi, true, expect, *s);
+                }
+                proven_pos = s->end_pos;
+            }
+            if (task_done) {
+                std::lock_guard<std::mutex> lk(mu);
+                ++consume_task;
+            }
+            cv_work.notify_all();
+            return s;
+        }
+        return nullptr;
+    }
     // Appends up to max_reads reads (and at most ~max_bytes bases); false when the input is exhausted.
-    bool fill(Batch &b, uint64_t max_reads, uint64_t max_bytes, bool keep) {
-        while (b.n() < max_reads && b.seq.size() < max_bytes)
-            if (!next(b, keep)) return false;
+    bool fill(Batch &b, uint64_t max_reads, uint64_t max_bytes) {
+        if (!started) die("ReadQueue::start was not called");
+        while (b.n() < max_reads && b.seq.size() < max_bytes) {
+            if (!cur) {
+                const uint64_t t0 = now_ns();
+                cur = next_segment();
+                ns_wait += now_ns() - t0;
+                cur_read = 0;
+                if (!cur) return false;
+            }
+            const size_t avail = cur->b.n() - cur_read;
+            size_t take = (size_t)std::min<uint64_t>(avail, max_reads - b.n());
+            if (take && max_bytes != ~0ull) {  // keep the byte bound (coarsely: per read)
+                size_t t = 0;
+                while (t < take && b.seq.size() + (cur->b.off[cur_read + t] - cur->b.off[cur_read]) < max_bytes) ++t;
+                take = std::max<size_t>(t, 1);
+            }
+            const uint64_t t0 = now_ns();
+            if (take) b.append(cur->b, cur_read, cur_read + take, keep);
+            ns_append += now_ns() - t0;
+            cur_read += take;
+            if (cur_read == cur->b.n()) {
+                if (!cur->err.empty()) {
+                    pending_error = cur->err;
+                    delete cur;
+                    cur = nullptr;
+                    return false;
+                }
+                recycle(cur);
+                cur = nullptr;
+            }
+        }
         return true;
+    }
+    std::string pending_error;  // malformed input reached: fatal once the reads before it have been processed
+
+    // PFQ_INGEST_TIMING=1: where the wall time of the reader went (stderr)
+    std::atomic<uint64_t> ns_parse{0}, ns_find{0}, ns_wait{0}, ns_append{0};
+    static uint64_t now_ns() {
+        return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    void report_timing() const {
+        if (!getenv("PFQ_INGEST_TIMING")) return;
+        fprintf(stderr, "ingest: %u workers, parse %.3f s (sum over workers), boundary search %.3f s, consumer waited %.3f s, appended %.3f s\n",
+                n_threads, ns_parse.load() * 1e-9, ns_find.load() * 1e-9, ns_wait.load() * 1e-9, ns_append.load() * 1e-9);
     }
 };
 
@@ -413,7 +805,7 @@ int cmd_query(int argc, char **argv) {
                              {"search-depth", 0, true}, {"pos-filter", 0, false}, {"neg-filter", 0, false}, {"format", 'F', true}};
     Args a = parse(argc, argv, 2, opts);
     const std::string reads = req(a, "reads"), out = req(a, "out"), db = req(a, "db-path");
-    (void)to_u64(opt(a, "threads", "4"), "threads");        // rayon pool size: no meaning on the device path
+    const unsigned threads = (unsigned)std::min<uint64_t>(to_u64(opt(a, "threads", "4"), "threads"), 256);  // rayon pool size in the reference; here: parser workers
     (void)to_u64(opt(a, "cache-size", "10"), "cache-size");  // LRU of .bf files: the whole tree is resident in HBM
     uint64_t block = to_u64(opt(a, "block-size-reads", "100"), "block-size-reads");
     const float threshold = to_f32(opt(a, "filter-threshold", "1.0"), "filter-threshold");
@@ -432,15 +824,26 @@ int cmd_query(int argc, char **argv) {
         check(pfq_tree_prune(tree, depth));
     }
     ReadQueue rq(reads, ov);
+    rq.start(filtering, threads);
 
     // create_and_overwrite_directory (main.rs:380-391): an existing output directory is deleted
     struct stat st;
     if (stat(out.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) rm_rf(out);
     mkdir(out.c_str(), 0777);
     const char *ext = rq.peek_format() == Fmt::Fastq ? "fq" : "fa";
-    FILE *pos_f = nullptr, *neg_f = nullptr;
-    if (pos && !(pos_f = fopen((out + "/POS_FILTERING." + ext).c_str(), "wb"))) die("cannot create POS_FILTERING in " + out);
-    if (neg && !(neg_f = fopen((out + "/NEG_FILTERING." + ext).c_str(), "wb"))) die("cannot create NEG_FILTERING in " + out);
+    int pos_fd = -1, neg_fd = -1;
+    uint64_t pos_size = 0, neg_size = 0;  // bytes written so far (formatters write their parts at computed offsets)
+    if (pos && (pos_fd = open((out + "/POS_FILTERING." + ext).c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666)) < 0)
+        die("cannot create POS_FILTERING in " + out);
+    if (neg && (neg_fd = open((out + "/NEG_FILTERING." + ext).c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666)) < 0)
+        die("cannot create NEG_FILTERING in " + out);
+    auto write_at = [](int fd, const std::string &buf, uint64_t at) {
+        for (size_t done = 0; done < buf.size();) {
+            ssize_t n = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(at + done));
+            if (n < 0) die(std::string("write error: ") + strerror(errno));
+            done += (size_t)n;
+        }
+    };
 
     const char *const *tax = nullptr;
     const uint64_t *cnt = nullptr;
@@ -448,93 +851,166 @@ int cmd_query(int argc, char **argv) {
     check(pfq_leaf_counts(tree, &tax, &cnt, &n_leaves));
     std::vector<std::string> leaf_names(tax, tax + n_leaves);
 
-    // The device processes big batches; ResultMap semantics (ids merged per reference block, cleared per block,
-    // main.rs:334-368) are applied per `block` consecutive reads so the outputs do not depend on the batch size.
     if (block == 0) block = 1;  // the reference would loop forever on empty blocks; treat 0 as 1
-    const uint64_t batch_reads = std::max<uint64_t>(block, 4u << 20) / block * block;
-    // Parsing runs on its own thread, one block ahead of the GPU (double buffering).
-    Batch batches[2];
-    std::mutex mu;
-    std::condition_variable cv;
-    int ready[2] = {0, 0};   // 0 = free for the parser, 1 = filled, 2 = filled and last
-    std::thread parser([&] {
-        bool more = true;
-        for (int i = 0; more; i ^= 1) {
+    const uint64_t t_loop0 = ReadQueue::now_ns();
+    uint64_t ns_gpu = 0, ns_out = 0, n_total = 0;
+    if (!filtering) {
+        // Counts only: the result does not depend on how the reads are cut into device calls (mapped_reads just
+        // accumulates, query.rs:143), so every parsed segment goes to the GPU as it is — no host-side copy.
+        while (Segment *sg = rq.next_segment()) {
+            const uint64_t n = sg->b.n();
+            if (n) {
+                sg->b.seq.resize(sg->b.seq.size() + 16);
+                const uint64_t tq0 = ReadQueue::now_ns();
+                check(pfq_query_batch(tree, sg->b.seq.data(), sg->b.off.data(), n, threshold, 0, nullptr));
+                ns_gpu += ReadQueue::now_ns() - tq0;
+                n_total += n;
+            }
+            if (!sg->err.empty()) {
+                rq.pending_error = sg->err;
+                delete sg;
+                break;
+            }
+            rq.recycle(sg);
+        }
+    } else {
+        // The device processes big batches; ResultMap semantics (ids merged per reference block, cleared per block,
+        // main.rs:334-368) are applied per `block` consecutive reads so the outputs do not depend on the batch size.
+        const uint64_t batch_reads = std::max<uint64_t>(block, 1u << 20) / block * block;
+        // Batches are assembled on their own thread, one ahead of the GPU (double buffering).
+        Batch batches[2];
+        std::mutex mu;
+        std::condition_variable cv;
+        int ready[2] = {0, 0};   // 0 = free for the assembler, 1 = filled, 2 = filled and last
+        std::thread parser([&] {
+            bool more = true;
+            for (int i = 0; more; i ^= 1) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return ready[i] == 0; });
+                }
+                batches[i].clear();
+                more = rq.fill(batches[i], batch_reads, 3ull << 30);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ready[i] = more ? 1 : 2;
+                }
+                cv.notify_all();
+            }
+        });
+        std::vector<std::string> pos_buf(threads), neg_buf(threads);
+        for (int i = 0;; i ^= 1) {
+            int state;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return ready[i] == 0; });
+                cv.wait(lk, [&] { return ready[i] != 0; });
+                state = ready[i];
             }
-            batches[i].clear();
-            more = rq.fill(batches[i], batch_reads, 3ull << 30, filtering);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                ready[i] = more ? 1 : 2;
-            }
-            cv.notify_all();
-        }
-    });
-    for (int i = 0;; i ^= 1) {
-        int state;
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return ready[i] != 0; });
-            state = ready[i];
-        }
-        Batch &b = batches[i];
-        const uint64_t n = b.n();
-        if (n) {
-            b.seq.resize(b.seq.size() + 16);
-            pfq_hits hits{};
-            check(pfq_query_batch(tree, b.seq.data(), b.off.data(), n, threshold, filtering ? PFQ_WANT_HITS : 0,
-                                  filtering ? &hits : nullptr));
-            if (filtering) {
-                std::string line;
-                for (uint64_t b0 = 0; b0 < n; b0 += block) {
-                    const uint64_t b1 = std::min(n, b0 + block);
-                    std::map<std::string, std::set<uint32_t>> result_map;  // read id -> leaf set (result_map.rs:20-22)
-                    for (uint64_t r = b0; r < b1; ++r)
-                        for (uint64_t j = hits.offsets[r]; j < hits.offsets[r + 1]; ++j) result_map[b.ids[r]].insert(hits.leaves[j]);
-                    for (uint64_t r = b0; r < b1; ++r) {
-                        auto it = result_map.empty() ? result_map.end() : result_map.find(b.ids[r]);
-                        FILE *f = it != result_map.end() ? pos_f : neg_f;  // read_mapped
-                        if (!f) continue;
-                        line.clear();
-                        line += b.has_qual[r] ? '@' : '>';  // write_record (main.rs:394-404)
-                        line += b.ids[r];
-                        if (it != result_map.end()) {       // get_ext_id: "{id} |{g1,g2}" (set order unspecified in the reference)
-                            line += " |";
-                            bool first = true;
-                            for (uint32_t leaf : it->second) {
-                                if (!first) line += ',';
-                                line += leaf_names[leaf];
-                                first = false;
+            Batch &b = batches[i];
+            const uint64_t n = b.n();
+            if (n) {
+                b.seq.resize(b.seq.size() + 16);
+                pfq_hits hits{};
+                const uint64_t tq0 = ReadQueue::now_ns();
+                check(pfq_query_batch(tree, b.seq.data(), b.off.data(), n, threshold, PFQ_WANT_HITS, &hits));
+                const uint64_t tq1 = ReadQueue::now_ns();
+                ns_gpu += tq1 - tq0;
+                n_total += n;
+                // Blocks are independent (the ResultMap is cleared per block): worker w formats a contiguous range of
+                // blocks into its own buffers, which are then written in order.
+                const uint64_t n_blocks = (n + block - 1) / block;
+                const unsigned nw = (unsigned)std::min<uint64_t>(std::max(1u, threads), n_blocks);
+                // two phases per worker: format, then (offsets known) write its part of both files
+                std::vector<uint64_t> pos_at(nw + 1, 0), neg_at(nw + 1, 0);
+                std::mutex fm;
+                std::condition_variable fcv;
+                unsigned formatted = 0;
+                auto format_range = [&](unsigned w) {
+                    std::string &pb = pos_buf[w], &nb = neg_buf[w];
+                    pb.clear();
+                    nb.clear();
+                    std::unordered_map<std::string_view, std::vector<uint32_t>> result_map;  // read id -> leaves (result_map.rs:20-22)
+                    for (uint64_t blk = n_blocks * w / nw; blk < n_blocks * (w + 1) / nw; ++blk) {
+                        const uint64_t b0 = blk * block, b1 = std::min(n, b0 + block);
+                        result_map.clear();
+                        for (uint64_t r = b0; r < b1; ++r) {
+                            if (hits.offsets[r] == hits.offsets[r + 1]) continue;
+                            std::vector<uint32_t> &v = result_map[b.id(r)];
+                            v.insert(v.end(), hits.leaves + hits.offsets[r], hits.leaves + hits.offsets[r + 1]);
+                        }
+                        for (auto &kv : result_map) {  // a set of genomes per id; printed in leaf order
+                            std::sort(kv.second.begin(), kv.second.end());
+                            kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
+                        }
+                        for (uint64_t r = b0; r < b1; ++r) {
+                            auto it = result_map.empty() ? result_map.end() : result_map.find(b.id(r));
+                            const bool mapped = it != result_map.end();  // read_mapped
+                            if (mapped ? !pos : !neg) continue;
+                            std::string &line = mapped ? pb : nb;
+                            line += b.has_qual[r] ? '@' : '>';  // write_record (main.rs:394-404)
+                            line.append(b.id(r));
+                            if (mapped) {                        // get_ext_id: "{id} |{g1,g2}" (set order unspecified in the reference)
+                                line += " |";
+                                bool first = true;
+                                for (uint32_t leaf : it->second) {
+                                    if (!first) line += ',';
+                                    line += leaf_names[leaf];
+                                    first = false;
+                                }
+                            }
+                            line += '\n';
+                            const size_t s0 = line.size();
+                            line.append((const char *)b.seq.data() + b.off[r], b.off[r + 1] - b.off[r]);
+                            for (size_t c = s0; c < line.size(); ++c) line[c] = (char)toupper((unsigned char)line[c]);  // main.rs:347-349
+                            line += '\n';
+                            if (b.has_qual[r]) {
+                                line += "+\n";
+                                line.append(b.quality(r));
+                                line += '\n';
                             }
                         }
-                        line += '\n';
-                        const size_t s0 = line.size();
-                        line.append((const char *)b.seq.data() + b.off[r], b.off[r + 1] - b.off[r]);
-                        for (size_t c = s0; c < line.size(); ++c) line[c] = (char)toupper((unsigned char)line[c]);  // main.rs:347-349
-                        line += '\n';
-                        if (b.has_qual[r]) {
-                            line += "+\n";
-                            line.append(b.qual.data() + b.off[r], b.off[r + 1] - b.off[r]);
-                            line += '\n';
-                        }
-                        fwrite(line.data(), 1, line.size(), f);
                     }
-                }
+                    {
+                        std::unique_lock<std::mutex> lk(fm);
+                        if (++formatted == nw) {  // last one in: every part's size is known
+                            pos_at[0] = pos_size;
+                            neg_at[0] = neg_size;
+                            for (unsigned x = 0; x < nw; ++x) {
+                                pos_at[x + 1] = pos_at[x] + pos_buf[x].size();
+                                neg_at[x + 1] = neg_at[x] + neg_buf[x].size();
+                            }
+                            fcv.notify_all();
+                        } else fcv.wait(lk, [&] { return formatted == nw; });
+                    }
+                    if (pos_fd >= 0) write_at(pos_fd, pb, pos_at[w]);
+                    if (neg_fd >= 0) write_at(neg_fd, nb, neg_at[w]);
+                };
+                std::vector<std::thread> fmt_threads;
+                for (unsigned w = 1; w < nw; ++w) fmt_threads.emplace_back(format_range, w);
+                format_range(0);
+                for (auto &t : fmt_threads) t.join();
+                pos_size = pos_at[nw];
+                neg_size = neg_at[nw];
+                ns_out += ReadQueue::now_ns() - tq1;
             }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ready[i] = 0;
+            }
+            cv.notify_all();
+            if (state == 2) break;
         }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            ready[i] = 0;
-        }
-        cv.notify_all();
-        if (state == 2) break;
+        parser.join();
     }
-    parser.join();
-    if (pos_f) fclose(pos_f);
-    if (neg_f) fclose(neg_f);
+    if (getenv("PFQ_INGEST_TIMING")) {
+        const double wall = (ReadQueue::now_ns() - t_loop0) * 1e-9;
+        fprintf(stderr, "query loop: %llu reads in %.3f s = %.2f M reads/s (pfq_query_batch %.3f s, output %.3f s)\n",
+                (unsigned long long)n_total, wall, n_total / wall * 1e-6, ns_gpu * 1e-9, ns_out * 1e-9);
+        rq.report_timing();
+    }
+    if (pos_fd >= 0) close(pos_fd);
+    if (neg_fd >= 0) close(neg_fd);
+    if (!rq.pending_error.empty()) die(rq.pending_error);  // the reads before the malformed record were processed
     check(pfq_save_leaf_counts(tree, (out + "/CLASSIFICATION.csv").c_str()));
     pfq_tree_close(tree);
     printf("Finished.\n");
@@ -568,11 +1044,14 @@ int cmd_build_balanced(int argc, char **argv) {
     const uint64_t s1 = strtoull(opt(a, "seed1", "81985529216486895").c_str(), nullptr, 0);
     const uint64_t s2 = strtoull(opt(a, "seed2", "18364758544493064720").c_str(), nullptr, 0);
     ReadQueue rq(genomes, to_fmt(opt(a, "format", "auto")));
+    rq.start(true, (unsigned)std::min<uint64_t>(to_u64(opt(a, "threads", "4"), "threads"), 256));
     Batch g;
-    while (rq.next(g, true)) {}  // block size 1 in the reference: one leaf per record (main.rs:148-200)
+    while (rq.fill(g, ~0ull, ~0ull)) {}  // block size 1 in the reference: one leaf per record (main.rs:148-200)
+    if (!rq.pending_error.empty()) die(rq.pending_error);
     std::vector<uint8_t> &seq = g.seq;
     std::vector<uint64_t> &off = g.off;
-    std::vector<std::string> &ids = g.ids;
+    std::vector<std::string> ids;
+    for (size_t r = 0; r < g.n(); ++r) ids.emplace_back(g.id(r));
     std::vector<const char *> idp;
     for (auto &s : ids) idp.push_back(s.c_str());
     const uint64_t nbits = needed_bits(fpr, largest);
@@ -584,6 +1063,56 @@ int cmd_build_balanced(int argc, char **argv) {
     check(pfq_tree_save(tree, db.c_str()));
     pfq_tree_close(tree);
     printf("Finished.\n");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ingest-check: parse the input exactly like `query` does and print what was read (no GPU involved).  Used by the
+// CPU tests to pin the parallel reader against a sequential one and against the reference's parsing rules.
+// ---------------------------------------------------------------------------------------------------------------
+int cmd_ingest_check(int argc, char **argv) {
+    std::vector<Opt> opts = {{"reads", 'r', true}, {"threads", 't', true}, {"format", 'F', true}, {"dump", 0, false},
+                             {"count", 0, false}, {"block-size-reads", 'b', true}};
+    Args a = parse(argc, argv, 2, opts);
+    ReadQueue rq(req(a, "reads"), to_fmt(opt(a, "format", "auto")));
+    const bool count_only = a.flags.count("count") != 0;  // what `query` without filtering keeps: bases and offsets only
+    rq.start(!count_only, (unsigned)std::min<uint64_t>(to_u64(opt(a, "threads", "4"), "threads"), 256));
+    const uint64_t block = std::max<uint64_t>(1, to_u64(opt(a, "block-size-reads", "1000000"), "block-size-reads"));
+    const bool dump = a.flags.count("dump") != 0;
+    uint64_t n = 0, bytes = 0, h = 0xcbf29ce484222325ull;
+    auto mix = [&](const void *p, size_t len) {
+        const unsigned char *c = (const unsigned char *)p;
+        for (size_t i = 0; i < len; ++i) h = (h ^ c[i]) * 0x100000001b3ull;
+        h = (h ^ 0xff) * 0x100000001b3ull;
+    };
+    Batch b;
+    bool more = true;
+    while (more) {
+        b.clear();
+        more = rq.fill(b, block, ~0ull);
+        if (count_only) {
+            n += b.n();
+            bytes += b.seq.size();
+            continue;
+        }
+        for (size_t r = 0; r < b.n(); ++r) {
+            const std::string_view id = b.id(r);
+            const uint64_t o = b.off[r], len = b.off[r + 1] - o;
+            mix(id.data(), id.size());
+            mix(b.seq.data() + o, len);
+            const std::string_view q = b.quality(r);
+            if (b.has_qual[r]) mix(q.data(), q.size());
+            if (dump) {
+                printf("%c%.*s\x01%.*s\x01%.*s\n", b.has_qual[r] ? '@' : '>', (int)id.size(), id.data(), (int)len,
+                       (const char *)b.seq.data() + o, (int)q.size(), q.data());
+            }
+            ++n;
+            bytes += len;
+        }
+    }
+    printf("reads=%llu bases=%llu fnv=%016llx\n", (unsigned long long)n, (unsigned long long)bytes, (unsigned long long)h);
+    rq.report_timing();
+    if (!rq.pending_error.empty()) die(rq.pending_error);
     return 0;
 }
 
@@ -613,6 +1142,7 @@ int main(int argc, char **argv) {
         if (i != first) av.push_back(argv[i]);
     if (cmd == "query") return cmd_query((int)av.size(), av.data());
     if (cmd == "build-balanced") return cmd_build_balanced((int)av.size(), av.data());
+    if (cmd == "ingest-check") return cmd_ingest_check((int)av.size(), av.data());
     if (cmd == "build" || cmd == "add")
         die("`" + cmd + "` (tree construction) is out of scope of the MI355X query path; use the reference binary, or build-balanced");
     usage();

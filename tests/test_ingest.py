@@ -1,0 +1,282 @@
+"""FASTA/FASTQ(.gz) ingest of the CLI (file_parser.rs:33-101,:191-344 on top of the bio 2.2.0 readers).
+
+CPU only: `phage_filter ingest-check` parses the input exactly like `query` does and prints what it read.  The
+expected records come from a plain sequential restatement of the rules of bio 2.2.0's readers written here (FASTA id =
+first whitespace-delimited token, FASTQ id = text up to the first blank; multi-line sequences; FASTQ quality = as
+many lines as the sequence had; trailing whitespace trimmed per line; no length check).  bio is not vendored in the
+reference, so multi-line / malformed behaviour is parity unpinned; four-line records are pinned by the reference's
+example reads (test_examples_fixture).  The parallel reader (chunks of a memory-mapped file, gzip streams side by side) must
+give byte-identical records in the same order for every thread count and chunk size — including files built to
+defeat record-boundary guessing (quality lines that start with '@' or '+', records longer than a chunk)."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "phagefilter_amd", "phage_filter")
+RNG = np.random.default_rng(20260417)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built_cli():
+    if not os.path.exists(CLI):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "phagefilter_amd", "csrc")])
+
+
+# ---- sequential restatement of the readers ------------------------------------------------------------------------
+def _lines(data: bytes):
+    if not data:
+        return []
+    parts = data.split(b"\n")
+    if parts[-1] == b"":
+        parts.pop()
+    return parts
+
+
+def _id(header: bytes, fastq: bool) -> bytes:
+    body = header.rstrip()[1:]
+    return body.split(b" ", 1)[0] if fastq else (body.split(None, 1)[0] if body and not body[:1].isspace() else b"")
+
+
+def parse_fasta(data: bytes):
+    recs, lines, i = [], _lines(data), 0
+    while i < len(lines):
+        assert lines[i][:1] == b">", "FASTA: Expected > at record start."
+        header, seq = lines[i], b""
+        i += 1
+        while i < len(lines) and lines[i][:1] != b">":
+            seq += lines[i].rstrip()
+            i += 1
+        recs.append((b">", _id(header, False), seq, b""))
+    return recs
+
+
+def parse_fastq(data: bytes, partial=False):
+    """Returns the records; with partial=True also whether a malformed record stopped the parse."""
+    recs, lines, i, bad = [], _lines(data), 0, None
+    while i < len(lines):
+        if lines[i][:1] != b"@":
+            bad = "Expected @"
+            break
+        header, seq, n_seq = lines[i], b"", 0
+        i += 1
+        while i < len(lines) and lines[i][:1] != b"+":
+            seq += lines[i].rstrip()
+            n_seq += 1
+            i += 1
+        i += 1                                        # the '+' line (or the end of the file)
+        qual = b""
+        for _ in range(n_seq):
+            if i < len(lines):
+                qual += lines[i].rstrip()
+                i += 1
+        if not qual:
+            bad = "Incomplete record"
+            break
+        recs.append((b"@", _id(header, True), seq, qual))
+    if partial:
+        return recs, bad
+    assert bad is None, bad
+    return recs
+
+
+def fnv(records):
+    h = 0xCBF29CE484222325
+    M = (1 << 64) - 1
+
+    def mix(h, b):
+        for c in b:
+            h = ((h ^ c) * 0x100000001B3) & M
+        return ((h ^ 0xFF) * 0x100000001B3) & M
+
+    for marker, rid, seq, qual in records:
+        h = mix(h, rid)
+        h = mix(h, seq)
+        if marker == b"@":
+            h = mix(h, qual)
+    return h
+
+
+def run_check(path, threads, chunk=None, fmt=None, seg=None, expect_rc=0):
+    env = dict(os.environ)
+    if chunk is not None:
+        env["PFQ_INGEST_CHUNK_BYTES"] = str(chunk)
+    if seg is not None:
+        env["PFQ_INGEST_SEGMENT_READS"] = str(seg)
+    cmd = [CLI, "ingest-check", "-r", str(path), "-t", str(threads), "--dump"]
+    if fmt:
+        cmd += ["-F", fmt]
+    p = subprocess.run(cmd, env=env, capture_output=True, timeout=120)
+    assert p.returncode == expect_rc, p.stderr.decode()
+    out = p.stdout.split(b"\n")
+    summary = [l for l in out if l.startswith(b"reads=")][0].decode().split()
+    recs = []
+    for l in out:
+        if l[:1] in (b">", b"@") and b"\x01" in l:
+            head, seq, qual = l.split(b"\x01")
+            recs.append((head[:1], head[1:], seq, qual))
+    return dict(kv.split("=") for kv in summary), recs, p.stderr.decode()
+
+
+def check_file(path, expected, fmt=None):
+    want = f"{fnv(expected):016x}"
+    for threads, chunk in [(1, None), (4, None), (1, 64), (3, 1), (8, 7), (5, 113), (8, 1000), (2, 4096)]:
+        summary, recs, _ = run_check(path, threads, chunk, fmt, seg=5)
+        assert recs == expected, (threads, chunk)
+        assert summary["reads"] == str(len(expected)) and summary["fnv"] == want, (threads, chunk)
+        assert summary["bases"] == str(sum(len(r[2]) for r in expected))
+
+
+# ---- generators ---------------------------------------------------------------------------------------------------
+def dna(n):
+    return bytes(RNG.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), n).astype(np.uint8))
+
+
+def tricky_fastq(n_records, *, multiline, crlf=False, final_newline=True):
+    """Quality strings drawn from an alphabet in which '@' and '+' are frequent, so that many quality lines look like
+    headers or separators; optional multi-line sequences/qualities with different wrapping."""
+    qalpha = np.frombuffer(b"@@@+++!IJ#5", dtype=np.uint8)
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n_records):
+        L = int(RNG.integers(1, 90)) if i % 7 else int(RNG.integers(300, 700))
+        seq = dna(L)
+        qual = bytes(RNG.choice(qalpha, L).astype(np.uint8))
+        header = (b"@r%d extra words /1" % i if i % 3 else b"@r%d" % i) if i % 11 else b"@r%d\ttab is part of a FASTQ id" % i
+        plus = b"+" if i % 2 else b"+r%d" % i
+        if multiline and L > 10:
+            w1 = int(RNG.integers(5, 61))
+            seq_lines = [seq[j:j + w1] for j in range(0, L, w1)]
+            # the reader takes as many quality lines as there were sequence lines, whatever their widths: cut the
+            # quality at other positions than the sequence
+            cuts = sorted(RNG.choice(np.arange(1, L), size=len(seq_lines) - 1, replace=False).tolist()) if len(seq_lines) > 1 else []
+            qual_lines = [qual[a:b] for a, b in zip([0] + cuts, cuts + [L])]
+        else:
+            seq_lines, qual_lines = [seq], [qual]
+        out.append(eol.join([header] + seq_lines + [plus] + qual_lines) + eol)
+    data = b"".join(out)
+    if not final_newline:
+        data = data[:-len(eol)]
+    return data
+
+
+def tricky_fasta(n_records, crlf=False):
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n_records):
+        L = int(RNG.integers(0, 400)) if i % 5 else int(RNG.integers(2000, 6000))
+        seq = dna(L)
+        w = int(RNG.integers(20, 81))
+        lines = [seq[j:j + w] for j in range(0, L, w)]
+        if i % 4 == 1:
+            lines.insert(len(lines) // 2, b"")          # blank line inside a record: an empty sequence line
+        if i % 6 == 2:
+            lines = [l + b"  " for l in lines]          # trailing blanks are trimmed
+        out.append(eol.join([b">g%d description here" % i] + lines) + eol)
+    return b"".join(out)
+
+
+# ---- tests --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("multiline,crlf,final_newline", [(False, False, True), (True, False, True), (True, True, True),
+                                                          (False, False, False), (True, False, False)])
+def test_fastq_chunked_equals_sequential(tmp_path, multiline, crlf, final_newline):
+    data = tricky_fastq(400, multiline=multiline, crlf=crlf, final_newline=final_newline)
+    p = tmp_path / "reads.fq"
+    p.write_bytes(data)
+    check_file(p, parse_fastq(data))
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_fasta_chunked_equals_sequential(tmp_path, crlf):
+    data = tricky_fasta(150, crlf=crlf)
+    p = tmp_path / "genomes.fasta"
+    p.write_bytes(data)
+    check_file(p, parse_fasta(data))
+
+
+def test_gzip_streams_and_directory_order(tmp_path):
+    """A directory is read file by file from the BACK of the sorted list (the reference pops from its Vec,
+    file_parser.rs:238), gzip and plain files mixed; records stream across files."""
+    d = tmp_path / "in"
+    d.mkdir()
+    blobs = {"a.fq": tricky_fastq(120, multiline=False), "b.fastq.gz": tricky_fastq(90, multiline=True),
+             "c.fq": tricky_fastq(1, multiline=False), "d.fq.gz": tricky_fastq(200, multiline=False), "ignored.txt": b"@x\nAC\n+\n!!\n",
+             "e.fq": b""}
+    for name, data in blobs.items():
+        (d / name).write_bytes(gzip.compress(data) if name.endswith(".gz") else data)
+    expected = []
+    for name in sorted(n for n in blobs if n != "ignored.txt")[::-1]:
+        expected += parse_fastq(blobs[name])
+    check_file(d, expected)
+
+
+def test_format_override_and_sniffing(tmp_path):
+    data = tricky_fasta(20)
+    p = tmp_path / "noext.fq"          # extension says FASTQ, content is FASTA: the first byte decides (file_parser.rs:33-66)
+    p.write_bytes(data)
+    check_file(p, parse_fasta(data))
+    check_file(p, parse_fasta(data), fmt="fasta")
+    _, _, err = run_check(p, 4, fmt="fastq", expect_rc=101)
+    assert "Expected @" in err
+
+
+def test_malformed_input_exits_like_a_panic_after_the_good_reads(tmp_path):
+    good = tricky_fastq(50, multiline=False)
+    cases = [(b"@x\nACGT\n", "Incomplete"),                      # no '+' line, no quality
+             (b"@x\nACGT\n+\n", "Incomplete"),                   # quality missing
+             (b"@x\n\n+\n\n@y\nAC\n+\n!!\n", "Incomplete"),     # empty sequence and quality
+             (b"ACGT\n", "Expected @"), (b"\n", "Expected @"),
+             (b"@x\nAC\nGT\n+\n!!!!\n@y\nAC\n+\n!!\n", "Expected @")]  # 2 sequence lines: the next header is eaten as quality
+    for bad, msg in cases:
+        p = tmp_path / "bad.fq"
+        p.write_bytes(good + bad)
+        want, why = parse_fastq(good + bad, partial=True)
+        assert why is not None and msg.startswith(why[:8])
+        for threads, chunk in [(1, None), (4, 64), (8, 1)]:
+            summary, recs, err = run_check(p, threads, chunk, expect_rc=101)
+            assert msg in err, (bad, err)
+            assert recs == want                     # everything before the malformed record was delivered
+    p = tmp_path / "bad.fa"
+    p.write_bytes(b"ACGT\n>a\nAC\n")
+    _, _, err = run_check(p, 2, expect_rc=101)
+    assert "Expected >" in err
+
+
+def test_wrong_boundary_guess_is_detected_and_repaired(tmp_path):
+    """A file built so that a false record start passes the two-record trial parse: three-line records whose first
+    sequence line and first quality line start with '@' and whose last quality line starts with '+'.  A chunk that
+    begins at such a quality line parses happily for a while; the consumer must notice that it does not start where
+    the previous chunk ended and parse it again from the proven position."""
+    recs = []
+    for i in range(300):
+        recs.append(b"@r%d\n@AAA%d\nCCCC\nGGGG\n+\n@III%d\nIIII\n+III\n" % (i, i % 10, i % 10))
+    data = b"".join(recs)
+    expected = parse_fastq(data)
+    assert len(expected) == 300 and expected[7] == (b"@", b"r7", b"@AAA7CCCCGGGG", b"@III7IIII+III")
+    p = tmp_path / "adversarial.fq"
+    p.write_bytes(data)
+    check_file(p, expected)
+
+
+def test_fastq_lengths_are_not_compared(tmp_path):
+    """bio's reader does not compare |sequence| and |quality| (that is Record::check(), which the reference never
+    calls, file_parser.rs:207-222): such records are classified and written like any other."""
+    data = b"@a 1\nACGTACGT\n+\n!!!\n@b\nAC\n+\nIIIIIIII\n"
+    p = tmp_path / "odd.fq"
+    p.write_bytes(data)
+    expected = [(b"@", b"a", b"ACGTACGT", b"!!!"), (b"@", b"b", b"AC", b"IIIIIIII")]
+    assert parse_fastq(data) == expected
+    check_file(p, expected)
+
+
+def test_examples_fixture(tmp_path):
+    """The reference's own example reads (committed subset under tests/golden/examples)."""
+    d = os.path.join(ROOT, "tests", "golden", "examples", "reads")
+    expected = []
+    for name in sorted(os.listdir(d))[::-1]:
+        expected += parse_fastq(open(os.path.join(d, name), "rb").read())
+    summary, recs, _ = run_check(d, 6, 5000)
+    assert recs == expected and summary["fnv"] == f"{fnv(expected):016x}"
