@@ -172,6 +172,12 @@ int pfq_synth_reads_device(uint8_t *d_out, uint64_t first_read, uint64_t n_reads
                            const uint8_t *d_genomes, uint64_t genome_len, uint64_t n_genomes, uint64_t seed,
                            void *stream);
 
+/* Page-locked host memory for the buffers handed to pfq_query_batch: the host-to-device copy then runs at PCIe rate
+ * instead of going through the runtime's pageable staging path.  (The reference keeps reads in ordinary Vec<u8>s,
+ * file_parser.rs:150-172; this is the transfer-side counterpart of that buffer.)  A tree must be open on the device. */
+int pfq_host_alloc(uint64_t bytes, void **out);
+int pfq_host_free(void *p);
+
 const char *pfq_last_error(void);
 const char *pfq_version(void);
 

@@ -14,7 +14,7 @@ SYMBOLS = [
     "pfq_tree_prune", "pfq_tree_close", "pfq_query_batch", "pfq_query_batch_device", "pfq_leaf_counts",
     "pfq_save_leaf_counts", "pfq_leaf_counts_export", "pfq_leaf_counts_import", "pfq_leaf_counts_reset",
     "pfq_last_stats", "pfq_set_path", "pfq_profile_begin", "pfq_profile_end", "pfq_debug_kmer_indices", "pfq_debug_node_filter", "pfq_synth_genomes_device",
-    "pfq_synth_reads_device", "pfq_last_error", "pfq_version",
+    "pfq_synth_reads_device", "pfq_host_alloc", "pfq_host_free", "pfq_last_error", "pfq_version",
 ]
 
 

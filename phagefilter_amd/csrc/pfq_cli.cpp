@@ -190,6 +190,33 @@ struct MemLines {
     uint64_t tell() const { return (uint64_t)(cur - base); }
 };
 
+// Bases and offsets of a batch go to the GPU as they are; when a tree is open their buffers are page-locked
+// (pfq_host_alloc) so that the copy runs at PCIe rate.  Small blocks and the CPU-only subcommands use malloc.
+bool g_pinned = false;  // set once, before the first batch is allocated
+template <class T>
+struct HostAlloc {
+    using value_type = T;
+    HostAlloc() = default;
+    template <class U>
+    HostAlloc(const HostAlloc<U> &) {}
+    static bool pinned(size_t n) { return g_pinned && n * sizeof(T) >= (1u << 20); }
+    T *allocate(size_t n) {
+        void *p = nullptr;
+        if (pinned(n)) {
+            if (pfq_host_alloc(n * sizeof(T), &p) != PFQ_OK) die(std::string("libpfq: ") + pfq_last_error());
+        } else if (!(p = malloc(n * sizeof(T)))) throw std::bad_alloc();
+        return (T *)p;
+    }
+    void deallocate(T *p, size_t n) {
+        if (pinned(n)) pfq_host_free(p);
+        else free(p);
+    }
+    template <class U>
+    bool operator==(const HostAlloc<U> &) const { return true; }
+    template <class U>
+    bool operator!=(const HostAlloc<U> &) const { return false; }
+};
+
 inline size_t trimmed_len(const char *p, size_t n) {  // str::trim_end
     while (n && isspace((unsigned char)p[n - 1])) --n;
     return n;
@@ -198,8 +225,8 @@ inline size_t trimmed_len(const char *p, size_t n) {  // str::trim_end
 // One block of reads in the layout the C ABI takes (concatenated bases + n+1 offsets); ids and qualities are kept
 // only when POS/NEG filtering needs them (the reference drops them otherwise too, file_parser.rs:202-204,217-220).
 struct Batch {
-    std::vector<uint8_t> seq;
-    std::vector<uint64_t> off{0};
+    std::vector<uint8_t, HostAlloc<uint8_t>> seq;
+    std::vector<uint64_t, HostAlloc<uint64_t>> off{0};
     std::vector<char> id_bytes;       // concatenated ids (bio Record::id()) when kept
     std::vector<uint64_t> id_off{0};
     std::vector<char> qual;           // concatenated qualities when kept (bio does not require |qual| == |seq|)
@@ -824,6 +851,9 @@ int cmd_query(int argc, char **argv) {
         check(pfq_tree_prune(tree, depth));
     }
     ReadQueue rq(reads, ov);
+    // Page-locking costs ~1.7 s per GB here (hipHostMalloc), the pageable copy ~0.1 s per GB: pinned buffers only
+    // pay off once every pooled buffer has been reused a few dozen times (inputs of >~ 10^9 reads).  Opt-in.
+    g_pinned = getenv("PFQ_PINNED") && atoi(getenv("PFQ_PINNED")) != 0;
     rq.start(filtering, threads);
 
     // create_and_overwrite_directory (main.rs:380-391): an existing output directory is deleted
@@ -1048,8 +1078,8 @@ int cmd_build_balanced(int argc, char **argv) {
     Batch g;
     while (rq.fill(g, ~0ull, ~0ull)) {}  // block size 1 in the reference: one leaf per record (main.rs:148-200)
     if (!rq.pending_error.empty()) die(rq.pending_error);
-    std::vector<uint8_t> &seq = g.seq;
-    std::vector<uint64_t> &off = g.off;
+    auto &seq = g.seq;
+    auto &off = g.off;
     std::vector<std::string> ids;
     for (size_t r = 0; r < g.n(); ++r) ids.emplace_back(g.id(r));
     std::vector<const char *> idp;

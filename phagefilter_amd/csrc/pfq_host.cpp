@@ -789,6 +789,17 @@ const char ORDER_NAME[] = "bitvec::order::Lsb0";
 // =================================================================================================================
 extern "C" {
 
+int pfq_host_alloc(uint64_t bytes, void **out) {
+    if (!out) return fail(PFQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return PFQ_OK;
+}
+int pfq_host_free(void *p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return PFQ_OK;
+}
+
 const char *pfq_last_error(void) { return g_err.c_str(); }
 const char *pfq_version(void) { return "libpfq 0.1 (gfx950)"; }
 

@@ -180,7 +180,7 @@ constexpr uint64_t SHORT_KMERS = 256;
 __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, const uint8_t *comp, const QueryArgs &a,
                                                  uint64_t r0, uint32_t n_in_group, uint32_t colmask, uint64_t &lane_len) {
     const uint32_t lane = lane_id(), j = lane >> 2, t = lane & 3u, k = a.hp.k;
-    const uint32_t rw = a.rw, slots = 64u >> a.rw_log2, word = lane & (rw - 1u), slot = lane >> a.rw_log2;
+    const uint32_t rw = a.rw;
     uint64_t o0 = 0, L = 0;
     if (j < n_in_group) {
         o0 = a.off[r0 + j];

@@ -123,7 +123,7 @@ def run_check(path, threads, chunk=None, fmt=None, seg=None, expect_rc=0):
 
 def check_file(path, expected, fmt=None):
     want = f"{fnv(expected):016x}"
-    for threads, chunk in [(1, None), (4, None), (1, 64), (3, 1), (8, 7), (5, 113), (8, 1000), (2, 4096)]:
+    for threads, chunk in [(1, None), (4, None), (3, 17), (8, 61), (5, 113), (2, 4096)]:
         summary, recs, _ = run_check(path, threads, chunk, fmt, seg=5)
         assert recs == expected, (threads, chunk)
         assert summary["reads"] == str(len(expected)) and summary["fnv"] == want, (threads, chunk)
@@ -183,7 +183,7 @@ def tricky_fasta(n_records, crlf=False):
 @pytest.mark.parametrize("multiline,crlf,final_newline", [(False, False, True), (True, False, True), (True, True, True),
                                                           (False, False, False), (True, False, False)])
 def test_fastq_chunked_equals_sequential(tmp_path, multiline, crlf, final_newline):
-    data = tricky_fastq(400, multiline=multiline, crlf=crlf, final_newline=final_newline)
+    data = tricky_fastq(200, multiline=multiline, crlf=crlf, final_newline=final_newline)
     p = tmp_path / "reads.fq"
     p.write_bytes(data)
     check_file(p, parse_fastq(data))
@@ -191,7 +191,7 @@ def test_fastq_chunked_equals_sequential(tmp_path, multiline, crlf, final_newlin
 
 @pytest.mark.parametrize("crlf", [False, True])
 def test_fasta_chunked_equals_sequential(tmp_path, crlf):
-    data = tricky_fasta(150, crlf=crlf)
+    data = tricky_fasta(80, crlf=crlf)
     p = tmp_path / "genomes.fasta"
     p.write_bytes(data)
     check_file(p, parse_fasta(data))
@@ -259,6 +259,14 @@ def test_wrong_boundary_guess_is_detected_and_repaired(tmp_path):
     p = tmp_path / "adversarial.fq"
     p.write_bytes(data)
     check_file(p, expected)
+
+
+def test_one_byte_chunks(tmp_path):
+    data = tricky_fastq(12, multiline=True)
+    p = tmp_path / "tiny.fq"
+    p.write_bytes(data)
+    summary, recs, _ = run_check(p, 8, 1)
+    assert recs == parse_fastq(data)
 
 
 def test_fastq_lengths_are_not_compared(tmp_path):
