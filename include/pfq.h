@@ -77,6 +77,21 @@ int pfq_tree_open(const char *db_dir, int device, pfq_tree **out);
  * guard columns, so results equal the reference's whole-tree traversal. */
 int pfq_tree_open_subtree(const char *db_dir, int device, uint64_t depth, uint64_t index, pfq_tree **out);
 
+/* The reference's `build` / `add` (main.rs:148-247) on the device.
+ * pfq_tree_create = BloomTree::new (bloom_tree.rs:100-118): an empty tree; filter geometry from
+ *   (false_pos_rate, largest_expected_genome) exactly like with_rate (bloom_filter.rs:229-240,:342-357, f32 arithmetic);
+ *   the two hash seeds are explicit (the reference draws them at random, hasher.rs:24-30).  expected_genomes sizes the
+ *   filter storage up front (2n-1 rows); 0 = grow on demand.
+ * pfq_tree_insert = BloomTree::insert (bloom_tree.rs:128-143): a leaf filter holding every canonical k-mer of `seq`
+ *   (:154-168), then the greedy descent (:187-214): every two-child node on the way absorbs the new filter and the walk
+ *   continues into the child at smaller Hamming distance (right only if strictly smaller, :201); the leaf reached is
+ *   replaced by a new internal node (left = old leaf, right = new leaf, filter = union, :226-245).  internal_name
+ *   names that node (tax_id, "<name>.bf"); NULL = "Internal_Node_<n>" with a running n unique in the tree (the
+ *   reference draws a random u16, :231-233).  Works on trees from pfq_tree_open as well (`add`). */
+int pfq_tree_create(uint64_t kmer_size, float false_pos_rate, uint32_t largest_expected_genome, uint64_t seed1,
+                    uint64_t seed2, uint64_t expected_genomes, int device, pfq_tree **out);
+int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char *tax_id, const char *internal_name);
+
 /* Synthetic balanced SBT built on the device: leaf i = all canonical k-mers of genome i
  * (what bloom_tree.rs:154-168 inserts), internal = OR of children (bloom_tree.rs:238-239), complete-as-possible
  * balanced shape, leaf tax_id = tax_ids[i], internal tax_id = "Internal_Node_<n>".  genomes/offsets are HOST

@@ -310,6 +310,83 @@ def build_balanced_tree(genomes: Sequence[bytes], tax_ids: Sequence[str], kmer_s
     return t
 
 
+def renumber_preorder(t: OracleTree) -> None:
+    """Nodes in pre-order (root = 0) again; filter rows stay where they are."""
+    order: List[int] = []
+    if t.root >= 0:
+        stack = [t.root]
+        while stack:
+            v = stack.pop()
+            order.append(v)
+            if t.right[v] >= 0:
+                stack.append(t.right[v])
+            if t.left[v] >= 0:
+                stack.append(t.left[v])
+    new_of = {v: i for i, v in enumerate(order)}
+    t.left, t.right, t.tax_id, t.bf_path, t.mapped_reads, t.filter_of = (
+        [new_of.get(t.left[v], -1) for v in order], [new_of.get(t.right[v], -1) for v in order],
+        [t.tax_id[v] for v in order], [t.bf_path[v] for v in order], [t.mapped_reads[v] for v in order],
+        [t.filter_of[v] for v in order])
+    t.root = 0 if order else -1
+
+
+def greedy_insert(t: OracleTree, genome: bytes, tax_id: str, internal_name: Optional[str] = None) -> None:
+    """BloomTree::insert (bloom_tree.rs:128-143): init_leaf_node (:154-168), add_to_tree (:187-214) and
+    init_internal_node (:226-245).  Filter rows are appended to t.bits; nodes are appended (call renumber_preorder
+    when done).  internal_name replaces the reference's random "Internal_Node_<u16>" (:231-233); default
+    "Internal_Node_<n>" with n counting the internal nodes made so far, skipping names already in the tree."""
+    def new_row() -> int:
+        t.bits = np.zeros((1, t.n_words), dtype=np.uint64) if t.bits is None or t.n_nodes == 0 else \
+            np.vstack([t.bits, np.zeros((1, t.n_words), dtype=np.uint64)])
+        return t.bits.shape[0] - 1
+
+    r = new_row()
+    nv = t.add_node(tax_id, f"{tax_id}.bf", r)
+    insert_sequence(t, r, genome)
+    if t.root < 0:
+        t.root = nv
+        return
+    cur, parent, went_right = t.root, -1, False
+    while True:
+        if t.left[cur] >= 0 and t.right[cur] >= 0:
+            t.bits[t.filter_of[cur]] |= t.bits[r]                                   # node_union(current, node), :195
+            dr = distance(t.bits[t.filter_of[t.right[cur]]], t.bits[r])            # :198
+            dl = distance(t.bits[t.filter_of[t.left[cur]]], t.bits[r])             # :199
+            parent, went_right = cur, dr < dl                                       # :201 ties go left
+            cur = t.right[cur] if went_right else t.left[cur]
+        elif t.is_leaf(cur):
+            if internal_name is None:
+                n = getattr(t, "_internal_counter", 0)
+                while f"Internal_Node_{n}.bf" in t.bf_path:
+                    n += 1
+                internal_name = f"Internal_Node_{n}"
+                t._internal_counter = n + 1
+            ri = new_row()
+            t.bits[ri] = t.bits[r] | t.bits[t.filter_of[cur]]                       # :236-237
+            ni = t.add_node(internal_name, f"{internal_name}.bf", ri, left=cur, right=nv)   # :241-242
+            if parent < 0:
+                t.root = ni
+            elif went_right:
+                t.right[parent] = ni
+            else:
+                t.left[parent] = ni
+            return
+        else:
+            raise RuntimeError("Node with only one child encountered - should not happen.")  # :209
+
+
+def build_greedy_tree(genomes: Sequence[bytes], tax_ids: Sequence[str], kmer_size: int, false_pos_rate: float,
+                      largest_expected_genome: int, seed1: int, seed2: int) -> OracleTree:
+    """`phage_filter build` (main.rs:148-200) with explicit seeds: BloomTree::new + insert per genome."""
+    nbits = needed_bits(false_pos_rate, largest_expected_genome)
+    t = OracleTree(kmer_size, nbits, optimal_num_hashes(nbits, largest_expected_genome), seed1, seed2, false_pos_rate,
+                   largest_expected_genome)
+    for g, i in zip(genomes, tax_ids):
+        greedy_insert(t, g, i)
+    renumber_preorder(t)
+    return t
+
+
 def query_batch(tree: OracleTree, reads: Sequence[bytes], threshold: float, *, faithful: bool = False,
                 threads: int = 1, want_hits: bool = True):
     """query::query_batch (query.rs:66-82).  Accumulates tree.mapped_reads; returns

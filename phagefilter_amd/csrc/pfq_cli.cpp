@@ -4,8 +4,8 @@
 // FASTA/FASTQ(.gz) ingest of src/file_parser.rs:33-101,:191-344 (bio 2.2.0 readers) and ResultMap
 // (src/result_map.rs:9-46).  All classification work happens on the GPU through include/pfq.h; this file only
 // parses text, keeps the reference's block bookkeeping and writes CLASSIFICATION.csv / POS_FILTERING.* /
-// NEG_FILTERING.*.  `build` / `add` (tree construction) are out of scope; `build-balanced` makes the synthetic
-// balanced tree of SURVEY §8d from a genome directory so the query path can be exercised end to end.
+// NEG_FILTERING.*.  `build` / `add` (main.rs:148-247) drive pfq_tree_create / pfq_tree_insert, the reference's greedy
+// placement on the device; `build-balanced` makes the synthetic balanced tree of SURVEY §8d from a genome directory.
 #include <dirent.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -25,6 +25,7 @@
 #include <deque>
 #include <map>
 #include <mutex>
+#include <random>
 #include <set>
 #include <thread>
 #include <string>
@@ -1097,6 +1098,70 @@ int cmd_build_balanced(int argc, char **argv) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// build / add (main.rs:148-247): one leaf per record, greedy placement by Hamming distance on the device
+// ---------------------------------------------------------------------------------------------------------------
+uint64_t random_seed() {  // HashSeed::new (hasher.rs:24-30) draws a random usize
+    std::random_device rd;
+    return ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+}
+int insert_genomes(pfq_tree *tree, const std::string &genomes, FmtOverride ov, unsigned threads) {
+    ReadQueue rq(genomes, ov);
+    rq.start(true, threads);
+    // the reference reads blocks of one record (ReadQueue::with_format(genomes, 1, …), main.rs:172,:229) and inserts
+    // them in input order
+    uint64_t n = 0;
+    while (Segment *sg = rq.next_segment()) {
+        for (size_t r = 0; r < sg->b.n(); ++r, ++n) {
+            const std::string id(sg->b.id(r));
+            check(pfq_tree_insert(tree, sg->b.seq.data() + sg->b.off[r], sg->b.off[r + 1] - sg->b.off[r], id.c_str(), nullptr));
+        }
+        if (!sg->err.empty()) die(sg->err);
+        rq.recycle(sg);
+    }
+    return (int)n;
+}
+int cmd_build(int argc, char **argv) {
+    std::vector<Opt> opts = {{"genomes", 'g', true}, {"db-path", 'd', true}, {"threads", 't', true}, {"kmer-size", 'k', true},
+                             {"cache-size", 'c', true}, {"false-pos-rate", 'f', true}, {"largest-genome", 'l', true},
+                             {"format", 'F', true}, {"seed1", 0, true}, {"seed2", 0, true}};
+    Args a = parse(argc, argv, 2, opts);
+    const std::string genomes = req(a, "genomes"), db = req(a, "db-path");
+    const uint64_t k = to_u64(opt(a, "kmer-size", "20"), "kmer-size");
+    const float fpr = to_f32(opt(a, "false-pos-rate", "0.001"), "false-pos-rate");
+    const uint32_t largest = (uint32_t)to_u64(opt(a, "largest-genome", "1000000"), "largest-genome");
+    (void)to_u64(opt(a, "cache-size", "10"), "cache-size");  // every filter stays in HBM while the tree is built
+    const unsigned threads = (unsigned)std::min<uint64_t>(to_u64(opt(a, "threads", "4"), "threads"), 256);
+    // --seed1/--seed2 are ours: the reference always draws the two hash seeds at random (bloom_tree.rs:114)
+    const uint64_t s1 = a.val.count("seed1") ? strtoull(a.val.at("seed1").c_str(), nullptr, 0) : random_seed();
+    const uint64_t s2 = a.val.count("seed2") ? strtoull(a.val.at("seed2").c_str(), nullptr, 0) : random_seed();
+    printf("Building the SBT...\n");
+    mkdir(db.c_str(), 0777);  // BloomTree::new creates the directory (bloom_tree.rs:107)
+    pfq_tree *tree = nullptr;
+    check(pfq_tree_create(k, fpr, largest, s1, s2, 0, device_from_env(), &tree));
+    insert_genomes(tree, genomes, to_fmt(opt(a, "format", "auto")), threads);
+    check(pfq_tree_save(tree, db.c_str()));
+    pfq_tree_close(tree);
+    printf("Finished.\n");
+    return 0;
+}
+int cmd_add(int argc, char **argv) {
+    std::vector<Opt> opts = {{"genomes", 'g', true}, {"db-path", 'd', true}, {"threads", 't', true}, {"cache-size", 'c', true},
+                             {"format", 'F', true}};
+    Args a = parse(argc, argv, 2, opts);
+    const std::string genomes = req(a, "genomes"), db = req(a, "db-path");
+    (void)to_u64(opt(a, "cache-size", "10"), "cache-size");
+    const unsigned threads = (unsigned)std::min<uint64_t>(to_u64(opt(a, "threads", "4"), "threads"), 256);
+    printf("Adding new genomes to the SBT...\n");
+    pfq_tree *tree = nullptr;
+    check(pfq_tree_open(db.c_str(), device_from_env(), &tree));
+    insert_genomes(tree, genomes, to_fmt(opt(a, "format", "auto")), threads);
+    check(pfq_tree_save(tree, db.c_str()));
+    pfq_tree_close(tree);
+    printf("Finished.\n");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // ingest-check: parse the input exactly like `query` does and print what was read (no GPU involved).  Used by the
 // CPU tests to pin the parallel reader against a sequential one and against the reference's parsing rules.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1151,8 +1216,10 @@ void usage() {
             "A fast, simple and memory efficient metagenomic filtering tool. (MI355X query path)\n\n"
             "Usage: phage_filter [-v...|-q...] <COMMAND>\n\nCommands:\n"
             "  query           Queries a set of reads. (ran after building the bloom tree)\n"
-            "  build-balanced  Builds a balanced synthetic BloomTree on the GPU (not the reference's greedy build)\n"
-            "  build, add      Not part of this build: tree construction stays with the reference binary\n");
+            "  build           Builds the BloomTree.\n"
+            "  add             Adds genomes to an already built BloomFilter.\n"
+            "  build-balanced  Builds a balanced synthetic BloomTree on the GPU (benchmark databases)\n"
+            "  ingest-check    Parses reads like `query` and prints what was read (no GPU)\n");
 }
 
 }  // namespace
@@ -1173,8 +1240,8 @@ int main(int argc, char **argv) {
     if (cmd == "query") return cmd_query((int)av.size(), av.data());
     if (cmd == "build-balanced") return cmd_build_balanced((int)av.size(), av.data());
     if (cmd == "ingest-check") return cmd_ingest_check((int)av.size(), av.data());
-    if (cmd == "build" || cmd == "add")
-        die("`" + cmd + "` (tree construction) is out of scope of the MI355X query path; use the reference binary, or build-balanced");
+    if (cmd == "build") return cmd_build((int)av.size(), av.data());
+    if (cmd == "add") return cmd_add((int)av.size(), av.data());
     usage();
     return 2;
 }

@@ -86,6 +86,11 @@ struct pfq_tree {
     bool superset_all = true;
     uint64_t shard_first_leaf = 0, tree_leaves = 0;  // subtree shards (pfq_tree_open_subtree)
     bool is_shard = false;
+    bool topology_dirty = false;       // nodes appended by pfq_tree_insert: renumber + verify before the next use
+    uint64_t internal_counter = 0;     // names of internal nodes created by pfq_tree_insert
+    size_t n_rows = 0, row_capacity = 0;  // filter rows in use / allocated in d_bits
+    DevBuf<uint32_t> d_build;          // insert scratch: leaf row, union triple
+    DevBuf<unsigned long long> d_dist; // insert scratch: Hamming distances (left, right)
     pfq::HashParams hp{};
     // ---- device: node-major filters
     DevBuf<uint64_t> d_bits;
@@ -319,8 +324,67 @@ int verify_supersets(pfq_tree &t) {
 }
 
 // Build the sliced matrix for the current leaf set.
+uint64_t needed_bits_f32(float rate, uint32_t items) {  // bloom_filter.rs:354-357, f32 arithmetic
+    const float ln2 = 0.693147180559945309417232121458176568f;
+    const float ln22 = ln2 * ln2;
+    const float v = roundf((float)items * (logf(1.0f / rate) / ln22));
+    return v <= 0 ? 0 : (uint64_t)v;
+}
+uint32_t optimal_num_hashes_f32(uint64_t bits, uint32_t items) {  // bloom_filter.rs:342-350
+    const float ln2 = 0.693147180559945309417232121458176568f;
+    const float v = roundf((float)bits / (float)items * ln2);
+    const uint32_t h = v <= 0 ? 0 : (uint32_t)v;
+    return std::min<uint32_t>(std::max<uint32_t>(h, 2), 200);
+}
+
+// Nodes in pre-order again (root = 0) after pfq_tree_insert appended some; parents, depths and the ⊇ flags follow.
+int finish_topology(pfq_tree &t) {
+    if (!t.topology_dirty) return PFQ_OK;
+    std::vector<int32_t> order, new_of(t.nodes.size(), -1);
+    if (t.root >= 0) {
+        std::vector<int32_t> st{t.root};
+        while (!st.empty()) {
+            const int32_t v = st.back();
+            st.pop_back();
+            new_of[v] = (int32_t)order.size();
+            order.push_back(v);
+            if (t.nodes[v].right >= 0) st.push_back(t.nodes[v].right);
+            if (t.nodes[v].left >= 0) st.push_back(t.nodes[v].left);
+        }
+    }
+    std::vector<Node> nn;
+    nn.reserve(order.size());
+    for (int32_t v : order) {
+        Node nd = std::move(t.nodes[v]);
+        if (nd.left >= 0) nd.left = new_of[nd.left];
+        if (nd.right >= 0) nd.right = new_of[nd.right];
+        nn.push_back(std::move(nd));
+    }
+    t.nodes.swap(nn);
+    t.root = t.nodes.empty() ? -1 : 0;
+    relink(t);
+    t.topology_dirty = false;
+    PFQ_TRY(verify_supersets(t));
+    return PFQ_OK;
+}
+
+// Room for `rows` filter rows in d_bits, keeping the rows in use.
+int reserve_rows(pfq_tree &t, size_t rows) {
+    if (rows <= t.row_capacity) return PFQ_OK;
+    size_t cap = std::max<size_t>(rows, t.row_capacity + t.row_capacity / 2 + 2);
+    uint64_t *p = nullptr;
+    HIP_TRY(hipMalloc(&p, cap * t.n_words * 8));
+    if (t.n_rows) HIP_TRY(hipMemcpy(p, t.d_bits.p, t.n_rows * t.n_words * 8, hipMemcpyDeviceToDevice));
+    t.d_bits.release();
+    t.d_bits.p = p;
+    t.d_bits.n = cap * t.n_words;
+    t.row_capacity = cap;
+    return PFQ_OK;
+}
+
 int build_layout(pfq_tree &t) {
     if (t.layout_valid) return PFQ_OK;
+    PFQ_TRY(finish_topology(t));
     t.leaves = leaves_dfs(t);
     const size_t nl = t.leaves.size();
     for (int32_t v : t.leaves)
@@ -723,6 +787,7 @@ int build_balanced_common(const uint8_t *d_genomes, const uint64_t *d_goff, uint
     for (auto &nd : t->nodes) t->filter_paths.push_back(nd.bf_path);
     if (nn) {
         HIP_TRY(t->d_bits.ensure(nn * t->n_words));
+        t->n_rows = t->row_capacity = nn;
         HIP_TRY(hipMemset(t->d_bits.p, 0, nn * t->n_words * 8));
         // leaves: genome order == left-to-right leaf order
         std::vector<int32_t> lv = leaves_dfs(*t);
@@ -907,6 +972,7 @@ static int open_impl(const char *db_dir, int device, bool shard, uint64_t shard_
             t->num_hashes = nh;
             PFQ_TRY(setup_hash_params(*t));
             HIP_TRY(t->d_bits.ensure(t->filter_paths.size() * t->n_words));
+            t->n_rows = t->row_capacity = t->filter_paths.size();
             first = false;
         }
         if (nbits != t->nbits || nh != t->num_hashes)
@@ -924,6 +990,119 @@ int pfq_tree_open(const char *db_dir, int device, pfq_tree **out) { return open_
 
 int pfq_tree_open_subtree(const char *db_dir, int device, uint64_t depth, uint64_t index, pfq_tree **out) {
     return open_impl(db_dir, device, true, depth, index, out);
+}
+
+// BloomTree::new (bloom_tree.rs:100-118) with explicit hash seeds: an empty tree whose filters are sized like
+// create_bloom_filter / with_rate (bloom_filter.rs:55-70,:229-240).
+int pfq_tree_create(uint64_t kmer_size, float false_pos_rate, uint32_t largest_expected_genome, uint64_t seed1, uint64_t seed2,
+                    uint64_t expected_genomes, int device, pfq_tree **out) {
+    if (!out) return fail(PFQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    PFQ_TRY(use_device(device));
+    std::unique_ptr<pfq_tree> t(new pfq_tree());
+    t->device = device;
+    t->kmer_size = kmer_size;
+    t->false_pos_rate = false_pos_rate;
+    t->largest_expected_genome = largest_expected_genome;
+    t->seed1 = seed1;
+    t->seed2 = seed2;
+    if (!(false_pos_rate > 0.0f) || largest_expected_genome == 0)
+        return fail(PFQ_ERR_ARG, "false_pos_rate must be > 0 and largest_expected_genome > 0");
+    t->nbits = needed_bits_f32(false_pos_rate, largest_expected_genome);
+    t->num_hashes = optimal_num_hashes_f32(t->nbits, largest_expected_genome);
+    PFQ_TRY(setup_hash_params(*t));
+    if (expected_genomes) PFQ_TRY(reserve_rows(*t, 2 * expected_genomes - 1));
+    *out = t.release();
+    return PFQ_OK;
+}
+
+// BloomTree::insert (bloom_tree.rs:128-143): init_leaf_node (:154-168) + add_to_tree (:187-214) + init_internal_node
+// (:226-245).  Internal nodes are named `internal_name` or "Internal_Node_<n>" with a running n that is unique in the
+// tree (the reference draws a random u16, :231-233, which can collide and then shares a .bf file between two nodes).
+int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char *tax_id, const char *internal_name) {
+    if (!tree || !tax_id || (len && !seq)) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    pfq_tree &t = *tree;
+    if (t.is_shard) return fail(PFQ_ERR_STATE, "a subtree shard cannot be extended");
+    if (t.n_words == 0) return fail(PFQ_ERR_STATE, "tree has no filter geometry");
+    PFQ_TRY(sync_counts_to_nodes(t));
+    t.layout_valid = false;
+    PFQ_TRY(reserve_rows(t, t.n_rows + 2));
+    HIP_TRY(t.d_build.ensure(8));
+    HIP_TRY(t.d_dist.ensure(2 * pfq::INSERT_STEP_BLOCKS));
+    std::vector<unsigned long long> part(2 * pfq::INSERT_STEP_BLOCKS);
+    // the new leaf's filter
+    const uint32_t new_row = (uint32_t)t.n_rows++;
+    HIP_TRY(hipMemsetAsync(t.d_bits.p + (uint64_t)new_row * t.n_words, 0, t.n_words * 8, nullptr));
+    HIP_TRY(t.d_seq.ensure(len + 16));
+    HIP_TRY(t.d_off.ensure(2));
+    const uint64_t goff[2] = {0, len};
+    if (len) HIP_TRY(hipMemcpy(t.d_seq.p, seq, len, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_off.p, goff, 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_build.p, &new_row, 4, hipMemcpyHostToDevice));
+    pfq::launch_insert(t.hp, t.d_seq.p, t.d_off.p, 1, t.d_build.p, t.d_bits.p, t.n_words, nullptr);
+    HIP_TRY(hipGetLastError());
+    Node leaf;
+    leaf.has_tax = true;
+    leaf.tax_id = tax_id;
+    leaf.bf_path = std::string(tax_id) + ".bf";
+    leaf.filter = new_row;
+    t.filter_paths.push_back(leaf.bf_path);
+    const int32_t nv = (int32_t)t.nodes.size();
+    t.nodes.push_back(leaf);
+    t.topology_dirty = true;
+    if (t.root < 0) {
+        t.root = nv;
+        return PFQ_OK;
+    }
+    int32_t cur = t.root, parent = -1;
+    bool went_right = false;
+    while (true) {
+        const Node &c = t.nodes[cur];
+        if (c.left >= 0 && c.right >= 0) {
+            pfq::launch_insert_step(t.d_bits.p, t.n_words, c.filter, new_row, t.nodes[c.left].filter, t.nodes[c.right].filter,
+                                    t.d_dist.p, nullptr);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(part.data(), t.d_dist.p, part.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long d[2] = {0, 0};
+            for (uint32_t b = 0; b < pfq::INSERT_STEP_BLOCKS; ++b) {
+                d[0] += part[2 * b];
+                d[1] += part[2 * b + 1];
+            }
+            parent = cur;
+            went_right = d[1] < d[0];  // `if right_distance < left_distance` (bloom_tree.rs:201): ties go left
+            cur = went_right ? c.right : c.left;
+        } else if (c.is_leaf()) {
+            std::string name;
+            if (internal_name) name = internal_name;
+            else {
+                do name = "Internal_Node_" + std::to_string(t.internal_counter++);
+                while (std::find(t.filter_paths.begin(), t.filter_paths.end(), name + ".bf") != t.filter_paths.end());
+            }
+            const uint32_t int_row = (uint32_t)t.n_rows++;
+            const uint32_t triple[3] = {int_row, c.filter, new_row};
+            HIP_TRY(hipMemcpy(t.d_build.p + 4, triple, 12, hipMemcpyHostToDevice));
+            pfq::launch_union(t.d_bits.p, t.n_words, t.d_build.p + 4, 1, nullptr);
+            HIP_TRY(hipGetLastError());
+            Node in;
+            in.has_tax = true;
+            in.tax_id = name;
+            in.bf_path = name + ".bf";
+            in.filter = int_row;
+            in.left = cur;   // the node already in the tree (bloom_tree.rs:241)
+            in.right = nv;   // the new leaf (:242)
+            t.filter_paths.push_back(in.bf_path);
+            const int32_t ni = (int32_t)t.nodes.size();
+            t.nodes.push_back(in);
+            if (parent < 0) t.root = ni;
+            else (went_right ? t.nodes[parent].right : t.nodes[parent].left) = ni;
+            break;
+        } else {
+            return fail(PFQ_ERR_FORMAT, "Node with only one child encountered - should not happen. (bloom_tree.rs:209)");
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return PFQ_OK;
 }
 
 int pfq_tree_build_balanced(const uint8_t *genomes, const uint64_t *offsets, uint64_t n_genomes, const char *const *tax_ids,
@@ -962,6 +1141,7 @@ int pfq_tree_build_balanced_device(const uint8_t *d_genomes, uint64_t genome_len
 int pfq_tree_save(const pfq_tree *tree, const char *db_dir) {
     if (!tree || !db_dir) return fail(PFQ_ERR_ARG, "null argument");
     PFQ_TRY(use_device(tree->device));
+    PFQ_TRY(finish_topology(*const_cast<pfq_tree *>(tree)));
     const pfq_tree &t = *tree;
     if (t.is_shard) return fail(PFQ_ERR_STATE, "a subtree shard is not a whole database and cannot be saved");
     std::string dir(db_dir);
@@ -1009,6 +1189,10 @@ int pfq_tree_save(const pfq_tree *tree, const char *db_dir) {
 
 int pfq_tree_info(const pfq_tree *tree, pfq_info *out) {
     if (!tree || !out) return fail(PFQ_ERR_ARG, "null argument");
+    if (tree->topology_dirty) {
+        PFQ_TRY(use_device(tree->device));
+        PFQ_TRY(finish_topology(*const_cast<pfq_tree *>(tree)));
+    }
     const pfq_tree &t = *tree;
     out->kmer_size = t.kmer_size;
     out->nbits = t.nbits;
@@ -1032,6 +1216,7 @@ int pfq_tree_prune(pfq_tree *tree, uint64_t search_depth) {
     if (!tree) return fail(PFQ_ERR_ARG, "null argument");
     PFQ_TRY(use_device(tree->device));
     pfq_tree &t = *tree;
+    PFQ_TRY(finish_topology(t));
     if (t.root < 0) return fail(PFQ_ERR_STATE, "prune_tree on an empty tree (reference: unwrap panic, bloom_tree.rs:310)");
     PFQ_TRY(sync_counts_to_nodes(t));
     relink(t);
@@ -1226,6 +1411,7 @@ int pfq_debug_kmer_indices(pfq_tree *tree, const uint8_t *seq, uint64_t len, uin
 int pfq_debug_node_filter(pfq_tree *tree, uint64_t node, uint64_t *out_words, uint64_t n_words) {
     if (!tree || !out_words) return fail(PFQ_ERR_ARG, "null argument");
     PFQ_TRY(use_device(tree->device));
+    PFQ_TRY(finish_topology(*tree));
     if (node >= tree->nodes.size() || n_words != tree->n_words) return fail(PFQ_ERR_ARG, "node / n_words out of range");
     HIP_TRY(hipMemcpy(out_words, tree->d_bits.p + (uint64_t)tree->nodes[node].filter * tree->n_words, n_words * 8,
                       hipMemcpyDeviceToHost));

@@ -145,6 +145,11 @@ void launch_insert(const HashParams &hp, const uint8_t *d_genomes, const uint64_
                    const uint32_t *d_leaf_row, uint64_t *bits, uint64_t n_words, hipStream_t st);
 // dst[i] = a[i] | b[i] over rows given as triples (dst,a,b); b == 0xffffffff: copy a.
 void launch_union(uint64_t *bits, uint64_t n_words, const uint32_t *d_triples, uint32_t n_triples, hipStream_t st);
+// bits[cur] |= bits[new]; per-block partial Hamming distances: sum_b d_out[2b] = hamming(bits[left], bits[new]),
+// sum_b d_out[2b+1] = hamming(bits[right], bits[new]), b < INSERT_STEP_BLOCKS
+constexpr uint32_t INSERT_STEP_BLOCKS = 1024;
+void launch_insert_step(uint64_t *bits, uint64_t n_words, uint32_t cur_row, uint32_t new_row, uint32_t left_row,
+                        uint32_t right_row, unsigned long long *d_out, hipStream_t st);
 // fail[e] != 0 iff child has a bit the parent lacks
 void launch_superset(const uint64_t *bits, uint64_t n_words, const uint32_t *d_edges /*(parent,child)*/, uint32_t n_edges,
                      uint32_t *d_fail, hipStream_t st);

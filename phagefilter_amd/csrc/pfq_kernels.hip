@@ -1225,6 +1225,45 @@ void launch_union(uint64_t *bits, uint64_t n_words, const uint32_t *d_triples, u
     hipLaunchKernelGGL(k_union, dim3(bx, n_triples), dim3(256), 0, st, bits, n_words, d_triples);
 }
 
+// One level of the reference's greedy placement (add_to_tree, bloom_tree.rs:187-214) in a single pass over four
+// filters: the internal node absorbs the new leaf (node_union), and the Hamming distances of the new leaf to both
+// children (bloom_filter.rs:142-149: popcount of the XOR over the raw words) are written as per-block partial sums
+// out[2b] (left), out[2b+1] (right).  A pure HBM-streaming kernel: 3 rows read + 1 row read-modify-written.
+__global__ void __launch_bounds__(256) k_insert_step(uint64_t *bits, uint64_t n_words, uint32_t cur_row, uint32_t new_row,
+                                                     uint32_t left_row, uint32_t right_row, unsigned long long *out) {
+    uint64_t *cur = bits + (uint64_t)cur_row * n_words;
+    const uint64_t *nw = bits + (uint64_t)new_row * n_words, *l = bits + (uint64_t)left_row * n_words,
+                   *r = bits + (uint64_t)right_row * n_words;
+    unsigned long long dl = 0, dr = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = nw[i];
+        cur[i] |= v;
+        dl += (unsigned long long)__popcll(l[i] ^ v);
+        dr += (unsigned long long)__popcll(r[i] ^ v);
+    }
+    // per-block partial sums, no atomics: 16 K same-address atomics cost 190 us here (one counter sustains ~88/us),
+    // twenty times the streaming itself; the host adds the INSERT_STEP_BLOCKS pairs
+    __shared__ unsigned long long s_l[4], s_r[4];
+    for (int d = 32; d > 0; d >>= 1) {
+        dl += __shfl_down(dl, d);
+        dr += __shfl_down(dr, d);
+    }
+    if (lane_id() == 0) {
+        s_l[threadIdx.x >> 6] = dl;
+        s_r[threadIdx.x >> 6] = dr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = s_l[0] + s_l[1] + s_l[2] + s_l[3];
+        out[2 * blockIdx.x + 1] = s_r[0] + s_r[1] + s_r[2] + s_r[3];
+    }
+}
+void launch_insert_step(uint64_t *bits, uint64_t n_words, uint32_t cur_row, uint32_t new_row, uint32_t left_row,
+                        uint32_t right_row, unsigned long long *d_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_insert_step, dim3(INSERT_STEP_BLOCKS), dim3(256), 0, st, bits, n_words, cur_row, new_row, left_row,
+                       right_row, d_out);
+}
+
 // parent ⊇ child per edge (the invariant that makes the tree walk pure pruning).
 __global__ void __launch_bounds__(256) k_superset(const uint64_t *bits, uint64_t n_words, const uint32_t *edges, uint32_t *fail) {
     const uint64_t *p = bits + (uint64_t)edges[2 * blockIdx.y] * n_words, *c = bits + (uint64_t)edges[2 * blockIdx.y + 1] * n_words;

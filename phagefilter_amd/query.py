@@ -64,6 +64,21 @@ class BloomTree:
         return cls(h, device)
 
     @classmethod
+    def new(cls, kmer_size: int, false_pos_rate: float, largest_expected_genome: int, seed1: int, seed2: int,
+            expected_genomes: int = 0, device: int = 0) -> "BloomTree":
+        """BloomTree::new (bloom_tree.rs:100-118) with explicit hash seeds; fill it with insert()."""
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().pfq_tree_create(kmer_size, false_pos_rate, largest_expected_genome, seed1, seed2,
+                                              expected_genomes, device, C.byref(h)))
+        return cls(h, device)
+
+    def insert(self, genome: bytes, tax_id: str, internal_name: Optional[str] = None) -> None:
+        """BloomTree::insert (bloom_tree.rs:128-143): greedy placement by Hamming distance, on the device."""
+        buf = np.frombuffer(genome, dtype=np.uint8) if len(genome) else np.zeros(1, dtype=np.uint8)
+        _ffi.check(_ffi.lib().pfq_tree_insert(self._h, buf.ctypes.data, len(genome), tax_id.encode(),
+                                              internal_name.encode() if internal_name is not None else None))
+
+    @classmethod
     def build_balanced(cls, genomes: Sequence[bytes], tax_ids: Sequence[str], kmer_size: int, nbits: int,
                        num_hashes: int, seed1: int, seed2: int, false_pos_rate: float = 0.001,
                        largest_expected_genome: int = 1000000, device: int = 0) -> "BloomTree":

@@ -184,3 +184,49 @@ def test_cli_errors_exit_like_a_panic(cli_db, tmp_path):
     assert p.returncode == 101 and "tree.bin" in p.stderr
     p = subprocess.run([CLI, "query", "-r", os.path.join(EX, "reads"), "-d", cli_db], capture_output=True, text=True)
     assert p.returncode == 101 and "--out" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_build_and_add_match_oracle(tmp_path):
+    """`phage_filter build` / `add` (main.rs:148-247): same database as the oracle's greedy insertion, record by
+    record in input order (directory files from the back of the sorted list), then queryable."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+
+    def dna(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).astype(np.uint8))
+
+    fam = [dna(900) for _ in range(4)]
+    recs = []
+    for i in range(14):
+        g = bytearray(fam[i % 4])
+        for _ in range(i):
+            g[int(rng.integers(0, len(g)))] = ord("ACGT"[int(rng.integers(0, 4))])
+        recs.append((f"genome{i}", bytes(g)))
+    gdir = tmp_path / "genomes"
+    gdir.mkdir()
+    (gdir / "a.fasta").write_bytes(b"".join(b">%s first batch\n%s\n" % (i.encode(), s) for i, s in recs[:5]))
+    (gdir / "b.fna").write_bytes(b"".join(b">%s\n%s\n%s\n" % (i.encode(), s[:400], s[400:]) for i, s in recs[5:9]))
+    more = tmp_path / "more.fa"
+    more.write_bytes(b"".join(b">%s\n%s\n" % (i.encode(), s) for i, s in recs[9:]))
+    order = recs[5:9] + recs[:5]          # b.fna is popped first
+    db = tmp_path / "db"
+    p = subprocess.run([CLI, "build", "-g", str(gdir), "-d", str(db), "-k", "15", "-f", "0.01", "-l", "2000", "--seed1", "5",
+                        "--seed2", "10"], capture_output=True, text=True)
+    assert p.returncode == 0 and "Building the SBT..." in p.stdout and "Finished." in p.stdout, p.stderr
+    ot = orc.build_greedy_tree([s for _, s in order], [i for i, _ in order], 15, 0.01, 2000, 5, 10)
+    assert fmt.encode_tree(fmt.read_db(str(db))) == fmt.encode_tree(ot)
+    p = subprocess.run([CLI, "add", "-g", str(more), "-d", str(db)], capture_output=True, text=True)
+    assert p.returncode == 0 and "Adding new genomes to the SBT..." in p.stdout, p.stderr
+    for i, s in recs[9:]:
+        orc.greedy_insert(ot, s, i)
+    orc.renumber_preorder(ot)
+    lt = fmt.read_db(str(db))
+    assert fmt.encode_tree(lt) == fmt.encode_tree(ot)
+    for v in range(ot.n_nodes):
+        assert np.array_equal(lt.bits[lt.filter_of[v]], ot.bits[ot.filter_of[v]])
+    # random seeds when none are given: two builds differ in their seeds, both are valid databases
+    p = subprocess.run([CLI, "build", "-g", str(more), "-d", str(tmp_path / "db2"), "-k", "15", "-l", "2000"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    t2 = fmt.read_db(str(tmp_path / "db2"))
+    assert (t2.seed1, t2.seed2) != (5, 10) and len(t2.leaves_dfs()) == 5

@@ -469,3 +469,99 @@ def test_subtree_shards_concatenate_to_whole_tree(gpu, tmp_path, depth, corrupt_
         assert next_leaf == len(want_counts)
         assert got_counts == want_counts, (depth, thr)
         assert sorted(got_hits) == want_hits, (depth, thr)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# `build` / `add`: the reference's greedy insertion (bloom_tree.rs:128-245) on the device
+# ---------------------------------------------------------------------------------------------------------------
+def _preorder(t):
+    """(is_leaf, tax_id) of an OracleTree's nodes in pre-order + its filters in that order."""
+    return [(t.is_leaf(v), t.tax_id[v]) for v in range(t.n_nodes)]
+
+
+def _gpu_greedy(genomes, ids, k, fpr, largest, seeds=(5, 10)):
+    gt = BloomTree.new(k, fpr, largest, seeds[0], seeds[1])
+    for g, i in zip(genomes, ids):
+        gt.insert(g, i)
+    return gt
+
+
+def _assert_same_database(gt, ot, tmp_path, name):
+    """Saved database == oracle tree: topology, names, leaf order and every node's filter."""
+    from oracle import pfq_format as fmt
+    d = tmp_path / name
+    d.mkdir()
+    gt.save(str(d))
+    lt = fmt.read_db(str(d))
+    assert _preorder(lt) == _preorder(ot)
+    assert lt.bf_path == ot.bf_path and (lt.kmer_size, lt.nbits, lt.num_hashes, lt.seed1, lt.seed2) == \
+        (ot.kmer_size, ot.nbits, ot.num_hashes, ot.seed1, ot.seed2)
+    assert (lt.left, lt.right) == (ot.left, ot.right)
+    for v in range(ot.n_nodes):
+        assert np.array_equal(lt.bits[lt.filter_of[v]], ot.bits[ot.filter_of[v]]), v
+        assert np.array_equal(gt.node_filter(v), ot.bits[ot.filter_of[v]]), v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("third,shape", [("ATCAG", "left"), ("TTTAG", "right")])
+def test_greedy_insert_reference_fixtures(gpu, tmp_path, third, shape):
+    """bloom_tree.rs:586-734 (test_nested_tree_insert_left / _right): the third genome equals the first (second), so it
+    is placed next to it whatever the hash seeds are."""
+    seqs = [("test1", b"ATCAG"), ("test2", b"TTTAG"), ("test3", third.encode())]
+    for seeds in ((5, 10), (0x0123456789ABCDEF, 0xFEDCBA9876543210)):
+        gt = _gpu_greedy([s for _, s in seqs], [i for i, _ in seqs], 5, 0.001, 1000, seeds)
+        info = gt.info()
+        assert (info.n_nodes, info.n_leaves, info.superset_verified) == (5, 3, 1)
+        leaves = [t for t, _ in gt.get_leaf_counts()]
+        assert leaves == (["test1", "test3", "test2"] if shape == "left" else ["test1", "test2", "test3"])
+        ot = orc.build_greedy_tree([s for _, s in seqs], [i for i, _ in seqs], 5, 0.001, 1000, *seeds)
+        _assert_same_database(gt, ot, tmp_path, f"db_{shape}_{seeds[0] & 0xff}")
+        gt.close()
+
+
+@pytest.mark.gpu
+def test_greedy_insert_empty_and_single(gpu, tmp_path):
+    """bloom_tree.rs:457-585 (test_empty_tree_insert / test_one_elem_tree_insert)."""
+    gt = BloomTree.new(5, 0.001, 1000, 5, 10)
+    assert gt.info().n_nodes == 0
+    gt.insert(b"ATCAGTTTAG", "only")
+    assert (gt.info().n_nodes, gt.info().n_leaves) == (1, 1)
+    gt.insert(b"TTTAGGGGGA", "second", internal_name="Internal_Node_77")
+    assert (gt.info().n_nodes, gt.info().n_leaves) == (3, 2)
+    assert [t for t, _ in gt.get_leaf_counts()] == ["only", "second"]   # old leaf left, new leaf right (bloom_tree.rs:241-242)
+    offs, leaves = gt.query_packed(*pack_reads([b"ATCAGTTTAG", b"TTTAGGGGGA", b"ACACACACAC"]), 1.0, want_hits=True)
+    assert hits_of(offs, leaves) == [(0, 0), (1, 1)]
+    gt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_genomes,k,fpr,largest", [(12, 9, 0.01, 400), (40, 15, 0.001, 3000), (90, 21, 0.001, 1200)])
+def test_greedy_build_matches_oracle_and_queries(gpu, tmp_path, n_genomes, k, fpr, largest):
+    """`build` then `add`: same topology, names and filters as the oracle's restatement of the greedy insertion, for
+    genome families (mutated copies cluster), unrelated genomes, very short ones and exact ties."""
+    base = [rand_dna(int(RNG.integers(200, 1200))) for _ in range(max(3, n_genomes // 4))]
+    genomes = []
+    for i in range(n_genomes):
+        g = bytearray(base[int(RNG.integers(0, len(base)))])
+        for _ in range(int(RNG.integers(0, 12))):
+            g[int(RNG.integers(0, len(g)))] = ord("ACGT"[int(RNG.integers(0, 4))])
+        genomes.append(bytes(g))
+    genomes[3] = genomes[2]                    # identical twin: distance 0
+    genomes[5] = b"ACGT"[: max(1, k - 6)]      # shorter than k: an empty filter (equidistant: ties go left)
+    ids = [f"g{i}" for i in range(n_genomes)]
+    first = n_genomes * 2 // 3
+    gt = _gpu_greedy(genomes[:first], ids[:first], k, fpr, largest)
+    ot = orc.build_greedy_tree(genomes[:first], ids[:first], k, fpr, largest, 5, 10)
+    _assert_same_database(gt, ot, tmp_path, "built")
+    gt.close()
+    # `add`: load the saved database and insert the rest
+    gt = BloomTree.load(str(tmp_path / "built"))
+    for g, i in zip(genomes[first:], ids[first:]):
+        gt.insert(g, i)
+        orc.greedy_insert(ot, g, i)
+    orc.renumber_preorder(ot)
+    _assert_same_database(gt, ot, tmp_path, "added")
+    reads = make_reads(genomes, 120, 40, 150, k)
+    for thr in (1.0, 0.5):
+        check_query(gt, ot, reads, thr)
+    gt.close()

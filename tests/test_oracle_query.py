@@ -110,3 +110,33 @@ def test_csv_format():  # query.rs:173-183
     lines = t.classification_csv().splitlines()
     assert "baseline,2" in lines and "diff,1" in lines
     assert all(not l.endswith(",0") for l in lines)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# greedy insertion (`build` / `add`): the reference's own fixtures, bloom_tree.rs:457-734
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seeds", [(5, 10), (0x0123456789ABCDEF, 0xFEDCBA9876543210), (1, 1)])
+def test_greedy_insert_reference_fixtures(seeds):
+    t = orc.build_greedy_tree([], [], 5, 0.001, 1000, *seeds)
+    assert t.root == -1 and t.n_nodes == 0
+    t = orc.build_greedy_tree([b"ATCAG"], ["test1"], 5, 0.001, 1000, *seeds)                     # :457-522
+    assert (t.n_nodes, t.is_leaf(0), t.tax_id[0], t.bf_path[0]) == (1, True, "test1", "test1.bf")
+    t = orc.build_greedy_tree([b"ATCAG", b"TTTAG"], ["test1", "test2"], 5, 0.001, 1000, *seeds)  # :523-585
+    assert [t.tax_id[v] for v in (t.left[0], t.right[0])] == ["test1", "test2"] and not t.is_leaf(0)
+    assert np.array_equal(t.bits[t.filter_of[0]], t.bits[t.filter_of[1]] | t.bits[t.filter_of[2]])
+    # :586-660 — the third genome equals the first: it joins it under the left child
+    t = orc.build_greedy_tree([b"ATCAG", b"TTTAG", b"ATCAG"], ["test1", "test2", "test3"], 5, 0.001, 1000, *seeds)
+    root = t.root
+    assert t.is_leaf(t.right[root]) and t.tax_id[t.right[root]] == "test2"
+    left = t.left[root]
+    assert sorted(t.tax_id[c] for c in (t.left[left], t.right[left])) == ["test1", "test3"]
+    # :661-734 — equals the second: joins it under the right child
+    t = orc.build_greedy_tree([b"ATCAG", b"TTTAG", b"TTTAG"], ["test1", "test2", "test3"], 5, 0.001, 1000, *seeds)
+    root = t.root
+    assert t.is_leaf(t.left[root]) and t.tax_id[t.left[root]] == "test1"
+    right = t.right[root]
+    assert sorted(t.tax_id[c] for c in (t.left[right], t.right[right])) == ["test2", "test3"]
+    # every internal filter is the union of its subtree's leaves
+    for v in range(t.n_nodes):
+        if not t.is_leaf(v):
+            assert np.array_equal(t.bits[t.filter_of[v]], t.bits[t.filter_of[t.left[v]]] | t.bits[t.filter_of[t.right[v]]])
