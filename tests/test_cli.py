@@ -230,3 +230,71 @@ def test_cli_build_and_add_match_oracle(tmp_path):
     assert p.returncode == 0, p.stderr
     t2 = fmt.read_db(str(tmp_path / "db2"))
     assert (t2.seed1, t2.seed2) != (5, 10) and len(t2.leaves_dfs()) == 5
+
+
+@pytest.mark.gpu
+def test_cli_accepts_benchmark_harness_invocations(tmp_path):
+    """the exact command lines of benchmarking/bench/tools/phage_filter.py:79-86 (build) and :105-116
+    (query), and the two output files its parse_output reads (:41-66) in the way it reads them — including the
+    harness's habit of opening POS_FILTERING.fa, which exists only for FASTA reads."""
+    import numpy as np
+    from collections import Counter
+    rng = np.random.default_rng(11)
+
+    def dna(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).astype(np.uint8))
+
+    genomes = [(f"NC_{1000 + i}.1", dna(3000)) for i in range(6)]
+    gdir = tmp_path / "genomes"
+    gdir.mkdir()
+    for name, seq in genomes:
+        (gdir / f"{name}.fna").write_bytes(b">%s some virus\n%s\n" % (name.encode(), seq))
+    # simulated reads are named <genome>_<n> (bench/simulate_reads.py) — parse_output strips the last '_' field
+    reads = []
+    for i in range(400):
+        g = int(rng.integers(0, 8))
+        if g < 6:
+            o = int(rng.integers(0, 3000 - 100))
+            reads.append((f"{genomes[g][0]}_{i}", genomes[g][1][o:o + 100].decode()))
+        else:
+            reads.append((f"random_{i}", dna(100).decode()))
+    fa = tmp_path / "reads.fa"
+    fa.write_text("".join(f">{rid}\n{seq}\n" for rid, seq in reads))
+    db, out = str(tmp_path / "db"), str(tmp_path / "out")
+    k, theta, threads = 20, 1.0, 4
+    build_cmd = [CLI, "build", "--genomes", str(gdir), "--db-path", db, "--kmer-size", f"{k}", "--cache-size", f"{100}",
+                 "--false-pos-rate", f"{0.00001}", "--largest-genome", f"{500000}", "--threads", f"{threads}"]
+    p = subprocess.run(build_cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    t = fmt.read_db(db)
+    assert (t.kmer_size, t.nbits, t.num_hashes) == (20, orc.needed_bits(0.00001, 500000), orc.optimal_num_hashes(orc.needed_bits(0.00001, 500000), 500000))
+    assert sorted(t.tax_id[v] for v in t.leaves_dfs()) == sorted(n for n, _ in genomes)
+    for depth, filter_reads in [(None, False), (None, True), (1, True)]:
+        run_cmd = [CLI, "query", "--reads", str(fa), "--db-path", db, "--filter-threshold", f"{theta}", "--cache-size", f"{1}",
+                   "--block-size-reads", f"{1000}", "--out", out, "--threads", f"{threads}"]
+        if depth is not None:
+            run_cmd += ["--search-depth", f"{depth}"]
+        if filter_reads:
+            run_cmd += ["--pos-filter"]
+        p = subprocess.run(run_cmd, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        # expected, from the oracle on the database the CLI built
+        ot = fmt.read_db(db)
+        if depth is not None:
+            ot.prune(depth)
+        hits, _, _ = orc.query_batch(ot, [s.encode() for _, s in reads], theta, threads=4)
+        if not filter_reads:                                   # parse_output, CLASSIFICATION.csv branch (:52-66)
+            name2counts = {}
+            for line in open(out + "/CLASSIFICATION.csv"):
+                name, count = line.strip("\n").split(",")
+                name2counts[name] = int(count)
+            assert name2counts == {n: c for n, c in ot.leaf_counts() if c > 0}
+            assert sum(name2counts.values()) >= sum(1 for rid, _ in reads if not rid.startswith("random"))
+        else:                                                  # parse_output, filter_reads branch (:41-51)
+            read_counter = Counter()
+            with open(out + "/POS_FILTERING.fa", "r") as f:
+                for line in f:
+                    if line[0] == ">":
+                        read_counter["_".join(line.strip(">").split(" ")[0].split("_")[:-1])] += 1
+            want = Counter("_".join(reads[r][0].split("_")[:-1]) for r in sorted({r for r, _ in hits}))
+            assert read_counter == want and sum(want.values()) >= 290
