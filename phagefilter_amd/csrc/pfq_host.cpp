@@ -580,7 +580,9 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 HIP_TRY(hipMemsetAsync(cnt, 0, nb * 4, st));
                 HIP_TRY(hipMemsetAsync(t.d_fail.p, 0, t.d_fail.n * 4, st));
                 HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 128 * 4, st));
+                a.batch_tails = (recs && !counts_mode && !getenv("PFQ_NO_TAIL_BATCH")) ? 1u : 0u;
                 pfq::launch_classify(a, true, counts_mode, blocks, st);
+                if (a.batch_tails) pfq::launch_tail_records(a, 2048, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
                 pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nb, st);
                 pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, sub_log2, t.d_sorted.p,

@@ -46,6 +46,7 @@ struct QueryArgs {
     uint64_t rec_cap;            // entries in recs (reads whose records would not fit are certified inline)
     uint32_t *long_list;         // thresholds < 1: reads of >= 256 k-mers, classified by a second launch (wider counters)
     unsigned int *n_long;
+    uint32_t batch_tails;        // theta == 1 with records: last windows of <= TAIL_KMERS k-mers are left to k_tail_records
     uint32_t one_pair_per_read;  // thresholds < 1: the per-k-mer miss bytes are indexed by read, so only a read's
                                  // first candidate is deferred (further candidates are certified inline)
 };
@@ -134,6 +135,7 @@ void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st);
 
 // launches (all asynchronous on `st`)
 void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int blocks, hipStream_t st);
+void launch_tail_records(const QueryArgs &a, int blocks, hipStream_t st);  // after launch_classify when a.batch_tails
 void launch_bucket_scan(const uint32_t *bucket_cnt, uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t n, hipStream_t st);
 void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
                            const uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t sub_log2, uint2 *sorted, uint4 *meta,

@@ -416,6 +416,12 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
     }
 }
 
+// A read's last window of records is made by k_tail_records when it holds at most TAIL_KMERS k-mers.
+__device__ __forceinline__ bool has_batched_tail(uint64_t n) {
+    const uint32_t tl = (uint32_t)(n & (WIN_KMERS - 1u));
+    return n > WIN_KMERS && n < (1ull << 32) && tl != 0 && tl <= TAIL_KMERS;
+}
+
 // ---- the classification kernel ---------------------------------------------------------------------------------------
 template <bool DEFER, bool COUNTS, bool LONG = false>
 __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
@@ -497,8 +503,12 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
                     ++st_def;
                     if (a.recs && !prepared) {  // hash the read once; every slice of the verify reuses the records
                         prepared = true;
+                        // 150 bp reads at k = 20..23 have 128 + (1..3) k-mers: a third hashing pass for two or three
+                        // k-mers.  Such last windows are left to k_tail_records (four reads per pass).
+                        const bool split_tail = a.batch_tails && has_batched_tail(rc.n);
                         for (uint64_t base = 0; base < rc.n; base += WIN_KMERS) {
                             uint32_t cnt = (uint32_t)((rc.n - base) < WIN_KMERS ? (rc.n - base) : WIN_KMERS);
+                            if (split_tail && base + WIN_KMERS > rc.n) break;
                             uint64_t h1 = w0_h1, h2 = w0_h2;
                             if (base != 0 || !have_w0) {
                                 stage_window(lds, wave, rc.read, base, cnt, a.hp.k);
@@ -604,6 +614,65 @@ void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int block
             hipLaunchKernelGGL((k_classify<false, true, true>), g, b, 0, st, a);
         } else hipLaunchKernelGGL((k_classify<false, false>), g, b, 0, st, a);
     }
+}
+
+// Records of the last windows k_classify<DEFER> left out (has_batched_tail): one pass serves four deferred pairs,
+// lane = (pair j of four, k-mer t of up to TAIL_KMERS).  Walks the deferred-pair buffer; a read deferred for two leaves
+// gets its tail records written twice (same values).
+__global__ void __launch_bounds__(256) k_tail_records(QueryArgs a) {
+    __shared__ uint32_t s_fw[WAVES_PER_BLOCK][4 * 96 / 4], s_rc[WAVES_PER_BLOCK][4 * 96 / 4];
+    __shared__ uint8_t s_comp[256];
+    fill_complement(s_comp);
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, k = a.hp.k;
+    const uint32_t j = lane >> 4, t = lane & 15u;
+    unsigned long long n_slots = *a.pair_cursor;
+    if (n_slots > a.pair_cap) n_slots = a.pair_cap;
+    uint32_t *tfw = s_fw[wave], *trc = s_rc[wave];
+    uint8_t *tfwd = reinterpret_cast<uint8_t *>(tfw), *trcb = reinterpret_cast<uint8_t *>(trc);
+    const uint64_t gw = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave, nw = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (uint64_t s0 = gw * 4u; s0 < n_slots; s0 += nw * 4u) {
+        const uint64_t slot = s0 + j;
+        uint32_t r = 0xffffffffu;
+        if (slot < n_slots) r = a.pairs[slot].x;
+        uint64_t o0 = 0, n = 0;
+        if (r != 0xffffffffu) {
+            o0 = a.off[r];
+            const uint64_t L = a.off[r + 1] - o0;
+            n = (L >= k) ? (L - k + 1) : 0;
+        }
+        const bool have = r != 0xffffffffu && has_batched_tail(n) && o0 + n <= a.rec_cap;
+        if (ballot64(have) == 0) continue;
+        const uint32_t tl = (uint32_t)(n & (WIN_KMERS - 1u));
+        const uint64_t base = n - tl;
+        const uint32_t W = have ? tl + k - 1u : 0u;  // <= TAIL_KMERS + KMAX - 1 = 79 bytes
+        const uint32_t mb = j * 96u + WIN_PAD;
+        const uint8_t *src = a.seq + (have ? o0 + base : 0ull);
+        __builtin_amdgcn_wave_barrier();
+        uint8_t b[5];
+#pragma unroll
+        for (uint32_t u = 0; u < 5; ++u) {
+            const uint32_t idx = 16u * u + t;
+            b[u] = src[idx < W ? idx : 0u];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 5; ++u) {
+            const uint32_t idx = 16u * u + t;
+            if (idx < W) {
+                tfwd[mb + idx] = b[u];
+                trcb[mb + (W - 1u - idx)] = s_comp[b[u]];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool valid = have && t < tl;
+        uint64_t h1, h2;
+        kmer_hashes_at(tfw, trc, mb + t, mb + (W - t - k), valid, a.hp, h1, h2);
+        const uint4 rec = make_probe_record(h1, h2, a.hp);
+        if (valid) a.recs[o0 + base + t] = rec;
+    }
+}
+void launch_tail_records(const QueryArgs &a, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_tail_records, dim3(blocks), dim3(256), 0, st, a);
 }
 
 // ---- bucketing of deferred (read, leaf) pairs by leaf --------------------------------------------------------------
