@@ -221,9 +221,10 @@ def main() -> None:
 
 def cpu_baseline(tree, reads, n_g, ids, B, rl, args, np, torch):
     """Oracle (`oracle/`, kind "port": a C restatement of the reference CPU path — the reference is Rust and cannot
-    be built here) timed on a bounded prefix of step 0's reads, same tree (copied back from HBM), all host cores."""
+    be built here) timed on a bounded prefix of step 0's reads, same tree (copied back from HBM), on this box's share of the host cores."""
     from oracle import pfq_oracle as orc
-    cores = len(os.sched_getaffinity(0))
+    # the CPU share of this box: 16 cores per visible GPU (a one-GPU box is a slice of a 256-core host), unless told
+    cores = int(os.environ.get("PFQ_BENCH_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16 * max(1, torch.cuda.device_count()))))
     ot = orc.balanced_topology(ids, K, NBITS, NUM_HASHES, SEEDS[0], SEEDS[1], 0.001, 5000000, alloc_bits=False)
     ot.bits = np.empty((ot.n_nodes, ot.n_words), dtype=np.uint64)
     for v in range(ot.n_nodes):

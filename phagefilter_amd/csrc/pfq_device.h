@@ -180,7 +180,7 @@ constexpr uint32_t MINI_BYTES = 84;                                  // >= WIN_P
 template <bool ENABLED>
 struct DenseLds {
     uint32_t mini[WAVES_PER_BLOCK][2][DENSE_READS * MINI_BYTES / 4];
-    uint32_t live[WAVES_PER_BLOCK][256];  // theta < 1: frontier words of the 256/rw reads of a group, [read][row word]
+    uint32_t live[WAVES_PER_BLOCK][DENSE_READS * 64];  // frontier words of the reads of a group, [read][row word]
 };
 template <>
 struct DenseLds<false> {

@@ -175,10 +175,12 @@ constexpr uint64_t SHORT_KMERS = 256;
 // ---- dense pre-screen (theta == 1) -------------------------------------------------------------------------------------
 // Most reads of a metagenome hit nothing, and the AND-frontier needs only their first four k-mers: a wave screens
 // DENSE_READS reads per pass with lane = (read, k-mer), so one hashing pass serves 16 reads instead of one.
-// Returns the mask of reads that must go through the per-read path: frontier not empty, or not a regular read
-// (no k-mers, need != n).  Reads outside the mask are finished: no leaf can pass them.
-__device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, const uint8_t *comp, const QueryArgs &a,
-                                                 uint64_t r0, uint32_t n_in_group, uint32_t colmask, uint64_t &lane_len) {
+// Returns the mask of regular reads whose frontier is not empty — their frontier words are left in
+// live_out[j*rw + w], so the per-read path does not gather them again — and in `irregular` the reads it did not
+// screen (no k-mers, need != n).  Reads in neither mask are finished: no leaf can pass them.
+__device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, const uint8_t *comp, uint32_t *live_out,
+                                                 const QueryArgs &a, uint64_t r0, uint32_t n_in_group, uint32_t colmask,
+                                                 uint32_t &irregular, uint64_t &lane_len) {
     const uint32_t lane = lane_id(), j = lane >> 2, t = lane & 3u, k = a.hp.k;
     const uint32_t rw = a.rw;
     uint64_t o0 = 0, L = 0;
@@ -217,6 +219,7 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
     const uint32_t i0v = mod_nbits(h1, a.hp), i1v = mod_nbits(h2, a.hp);
     const bool two = a.hp.num_hashes > 1;
     uint32_t survive = 0;
+    irregular = 0;
     // Row gathers, 16 bytes per lane: a read's 2*nk rows of rw dwords are covered by lanes (row = lane / (rw/4),
     // part = lane % (rw/4)); with rw = 32 one load instruction fetches all 8 rows of a read.  The loads of
     // DENSE_BATCH reads are issued before any is consumed.  (rw >= 4 here; smaller trees skip the pre-screen.)
@@ -258,7 +261,7 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
             if (jj >= n_in_group) continue;
             const uint32_t nk_j = bcast_u32(nk, (int)(jj * 4u));
             if (nk_j == 0) {  // irregular read: leave it to the per-read path
-                survive |= 1u << jj;
+                irregular |= 1u << jj;
                 continue;
             }
             uint4 l4 = acc[u];
@@ -268,10 +271,14 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
                 l4.z &= (uint32_t)__shfl_xor((int)l4.z, (int)sft);
                 l4.w &= (uint32_t)__shfl_xor((int)l4.w, (int)sft);
             }
-            const bool any = ((l4.x & cm[0]) | (l4.y & cm[1]) | (l4.z & cm[2]) | (l4.w & cm[3])) != 0;
-            if (ballot64(any)) survive |= 1u << jj;
+            l4.x &= cm[0]; l4.y &= cm[1]; l4.z &= cm[2]; l4.w &= cm[3];
+            if (ballot64((l4.x | l4.y | l4.z | l4.w) != 0)) {
+                survive |= 1u << jj;
+                if (rsel == 0) *reinterpret_cast<uint4 *>(live_out + jj * rw + part * 4u) = l4;
+            }
         }
     }
+    __builtin_amdgcn_wave_barrier();
     return survive;
 }
 
@@ -472,6 +479,7 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             else if (rc.n < (1ull << NPLANES)) live = screen_counts_p<NPLANES, 8>(lds, wave, a, rc, colmask);
             else live = colmask;  // counters too narrow: no screening, certify every leaf
         }
+        else if (rc.maxmiss == 0 && pre) live = pre[word] & colmask;  // frontier from the dense pre-screen
         else if (rc.maxmiss == 0) { live = screen_all(lds, wave, a, rc, colmask, w0_h1, w0_h2); have_w0 = true; }
         else live = colmask;
 
@@ -548,11 +556,18 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             const uint64_t r0 = g * DENSE_READS;
             const uint32_t cnt = (uint32_t)(a.n_reads - r0 < DENSE_READS ? a.n_reads - r0 : DENSE_READS);
             uint64_t lane_len;
-            uint32_t survive = dense_screen(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, a, r0, cnt, colmask, lane_len);
-            if (!((survive >> (lane >> 2)) & 1u)) dense_bytes += lane_len;  // reads finished here still count their bytes
+            uint32_t irregular;
+            uint32_t survive = dense_screen(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, r0, cnt, colmask,
+                                            irregular, lane_len);
+            if (!(((survive | irregular) >> (lane >> 2)) & 1u)) dense_bytes += lane_len;  // reads finished here still count their bytes
             while (survive) {
                 const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
                 survive &= survive - 1u;
+                process_read(r0 + jj, dlds.live[wave] + jj * rw);
+            }
+            while (irregular) {
+                const uint32_t jj = (uint32_t)__ffs((int)irregular) - 1u;
+                irregular &= irregular - 1u;
                 process_read(r0 + jj, nullptr);
             }
         }
