@@ -983,9 +983,10 @@ void launch_tile_plan(const TileArgs &a, hipStream_t st) {
     if (a.n_leaves) hipLaunchKernelGGL(k_tile_plan, dim3(a.n_leaves), dim3(256), 0, st, a);
 }
 
-constexpr uint32_t BIN_WAVES = 8;       // pairs binned per round by one block (4 with 64-entry bins measured slower and spills more)
-constexpr uint32_t BIN_CAP = 128;       // LDS entries per tile and round (mean ~75 at 150 bp / 138 tiles, +6 sigma)
-constexpr uint32_t BIN_STRIDE = BIN_CAP + 1;  // odd stride: bins fill in step, so slot s of every tile would share a bank
+// BIN_WAVES pairs are binned per round by one block, BIN_CAP LDS entries per tile and round (mean ~75 per 8 pairs at
+// 150 bp / 138 tiles, +6 sigma).  Two builds: 16 waves x 256 entries when the bins of all tiles fit the LDS (one block
+// per CU: twice as long runs per flush, half the rounds), else 8 x 128 (4 x 64 measured slower and spills more).
+// BIN_STRIDE is odd: the bins fill in step, so slot s of every tile would share a bank.
 constexpr uint32_t NO_PAIR = 0xfffffffeu;
 __device__ __forceinline__ void flag_fallback(const TileArgs &a, uint32_t e) {
     if (!(atomicOr(&a.fail[e], 2u) & 2u)) {
@@ -993,7 +994,9 @@ __device__ __forceinline__ void flag_fallback(const TileArgs &a, uint32_t e) {
         if (pos < a.flag_cap) a.flag_list[pos] = e;
     }
 }
+template <uint32_t BIN_WAVES, uint32_t BIN_CAP>
 __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
+    constexpr uint32_t BIN_STRIDE = BIN_CAP + 1;
     extern __shared__ uint32_t s_dyn[];   // cnt[MAX_TILES] then bins[n_tiles][BIN_CAP]
     __shared__ uint32_t s_wc[BIN_WAVES];
     __shared__ uint32_t s_pos[MAX_TILES];
@@ -1129,13 +1132,19 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
     }
 }
 void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
-    size_t lds = (MAX_TILES + (size_t)a.n_tiles * BIN_STRIDE) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<8, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<16, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_tile_bin, dim3(blocks), dim3(BIN_WAVES * 64), lds, st, a);
+    const size_t lds_wide = (MAX_TILES + (size_t)a.n_tiles * 257) * 4;
+    if (lds_wide <= 148 * 1024 && !getenv("PFQ_BIN_NARROW")) {
+        hipLaunchKernelGGL((k_tile_bin<16, 256>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_wide, st, a);
+    } else {
+        const size_t lds = (MAX_TILES + (size_t)a.n_tiles * 129) * 4;
+        hipLaunchKernelGGL((k_tile_bin<8, 128>), dim3(blocks), dim3(8 * 64), lds, st, a);
+    }
 }
 
 __global__ void __launch_bounds__(512) k_tile_test(TileArgs a) {
