@@ -565,3 +565,28 @@ def test_greedy_build_matches_oracle_and_queries(gpu, tmp_path, n_genomes, k, fp
     for thr in (1.0, 0.5):
         check_query(gt, ot, reads, thr)
     gt.close()
+
+
+@pytest.mark.gpu
+def test_page_locked_host_buffers(gpu):
+    """pfq_host_alloc / pfq_host_free: the batch handed to pfq_query_batch may live in page-locked memory."""
+    import ctypes as C
+    from phagefilter_amd import _ffi
+    genomes = [rand_dna(600) for _ in range(5)]
+    ot, ids = oracle_tree(genomes, 21, 60013, 5)
+    gt = gpu_tree(genomes, ids, 21, 60013, 5)
+    reads = make_reads(genomes, 60, 20, 150, 21)
+    seq, off = pack_reads(reads)
+    L = _ffi.lib()
+    p_seq, p_off = C.c_void_p(), C.c_void_p()
+    _ffi.check(L.pfq_host_alloc(seq.nbytes + 16, C.byref(p_seq)))
+    _ffi.check(L.pfq_host_alloc(off.nbytes, C.byref(p_off)))
+    C.memmove(p_seq, seq.ctypes.data, seq.nbytes)
+    C.memmove(p_off, off.ctypes.data, off.nbytes)
+    _ffi.check(L.pfq_query_batch(gt._h, p_seq, p_off, len(reads), 1.0, 0, None))
+    orc.query_batch(ot, reads, 1.0)
+    assert gt.get_leaf_counts() == ot.leaf_counts()
+    _ffi.check(L.pfq_host_free(p_seq))
+    _ffi.check(L.pfq_host_free(p_off))
+    _ffi.check(L.pfq_host_free(None))
+    gt.close()
