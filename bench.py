@@ -188,7 +188,11 @@ def main() -> None:
                        "parallelism": f"reads sharded x{world}, tree replicated per GPU, one RCCL all-reduce of per-genome counts"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom, "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": alg},
+                         "algorithmic_bytes_per_launch": alg,
+                         # SURVEY §8d's whole-path form: sum of A(r) over the reads of a step / time of a step (per GPU)
+                         "whole_path": {"achieved": int(st.algorithmic_bytes) / (elapsed / args.steps) / 1e9, "unit": "GB/s",
+                                        "frac": int(st.algorithmic_bytes) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                        "algorithmic_bytes_per_step": int(st.algorithmic_bytes)}},
             "query_path": "bucketed(screen+L2-sliced verify)" if st.path == 1 else "direct",
             "n_slices": int(st.n_slices), "tile_mode": int(st.tile_mode), "fallback_pairs": int(st.n_fallback_pairs),
             "tile_chunks": int(st.n_chunks), "tile_entries": int(st.tile_entries),
