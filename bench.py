@@ -74,6 +74,19 @@ def main() -> None:
     genomes = torch.empty(n_g * glen, dtype=torch.uint8, device=dev)
     _ffi.check(L.pfq_synth_genomes_device(genomes.data_ptr(), n_g, glen, GENOME_SEED, None))
     torch.cuda.synchronize()
+    fam = int(os.environ.get("PFQ_BENCH_FAMILY", "0"))
+    if fam > 1:  # experiment: families of `fam` related genomes (PFQ_BENCH_DIVERGENCE substitutions per base, default
+        # 0.001) so that a positive read passes several leaves
+        div = float(os.environ.get("PFQ_BENCH_DIVERGENCE", "0.001"))
+        g2 = genomes.view(n_g, glen)
+        base = g2[(torch.arange(n_g, device=dev) // fam) * fam].clone()
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(12345)
+        mut = torch.rand(n_g, glen, device=dev, generator=gen) < div
+        alt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (n_g, glen), device=dev, generator=gen)]
+        g2.copy_(torch.where(mut, alt, base))
+        del base, mut, alt
+        torch.cuda.synchronize()
     tree = BloomTree.build_balanced_device(genomes.data_ptr(), glen, n_g, ids, K, NBITS, NUM_HASHES, SEEDS[0], SEEDS[1],
                                            0.001, 5000000, device=dev_index)
     tree.set_path(args.path)

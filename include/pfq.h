@@ -155,6 +155,7 @@ typedef struct pfq_stats {
     uint32_t tile_mode;         /* 1: certificates tested out of LDS tiles (k_tile_*), k_verify_rec only as fallback */
     uint32_t n_fallback_pairs;  /* pairs the LDS-tile pass could not bin (certified by the fallback kernel) */
     uint64_t n_chunks, tile_entries;
+    uint32_t tile_passes_launched, tile_passes_needed;  /* LDS-tile stage: passes over the reused probe buckets */
 } pfq_stats;
 int pfq_last_stats(pfq_tree *tree, pfq_stats *out);
 /* Force a query path: -1 auto, 0 direct, 1 bucketed. */

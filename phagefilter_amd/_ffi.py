@@ -40,7 +40,8 @@ class Stats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_candidates", C.c_uint64), ("n_hits", C.c_uint64),
                 ("n_allhit_reads", C.c_uint64), ("algorithmic_bytes", C.c_uint64), ("path", C.c_uint32),
                 ("n_slices", C.c_uint32), ("tile_mode", C.c_uint32), ("n_fallback_pairs", C.c_uint32),
-                ("n_chunks", C.c_uint64), ("tile_entries", C.c_uint64)]
+                ("n_chunks", C.c_uint64), ("tile_entries", C.c_uint64), ("tile_passes_launched", C.c_uint32),
+                ("tile_passes_needed", C.c_uint32)]
 
 
 class Profile(C.Structure):

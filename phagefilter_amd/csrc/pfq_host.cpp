@@ -86,6 +86,12 @@ struct pfq_tree {
     bool superset_all = true;
     uint64_t shard_first_leaf = 0, tree_leaves = 0;  // subtree shards (pfq_tree_open_subtree)
     bool is_shard = false;
+    // deferred pairs per read seen by recent calls (related genomes: a read passes several leaves): sizes the pair
+    // buffer and the probe buckets of the next call.  The cursor of a call lands in pinned memory asynchronously.
+    unsigned long long *h_pair_cursor = nullptr;
+    hipEvent_t hint_ev = nullptr;
+    uint64_t hint_reads = 0, hint_entry_cap = 0, passes_hint = 1;
+    double pairs_per_read = 1.0;
     bool topology_dirty = false;       // nodes appended by pfq_tree_insert: renumber + verify before the next use
     uint64_t internal_counter = 0;     // names of internal nodes created by pfq_tree_insert
     size_t n_rows = 0, row_capacity = 0;  // filter rows in use / allocated in d_bits
@@ -107,7 +113,7 @@ struct pfq_tree {
     DevBuf<uint32_t> d_entries, d_pair_chunk, d_leaf_chunk0, d_flag_list;  // LDS-tile certificates
     DevBuf<pfq::ChunkDesc> d_chunks;
     DevBuf<unsigned int> d_gfill;
-    uint32_t last_tile_mode = 0;
+    uint32_t last_tile_mode = 0, last_passes = 1;
     DevBuf<uint2> d_hit_pairs, d_pairs, d_sorted;
     DevBuf<uint32_t> d_bucket, d_fail;  // bucket: cnt[n], off[n+1], cur[n]
     DevBuf<unsigned int> d_queue;
@@ -466,7 +472,20 @@ int ensure_scratch(pfq_tree &t, uint64_t n_reads, bool want_hits) {
     return PFQ_OK;
 }
 int ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads) {
-    const uint64_t cap = 2 * n_reads + 32 * 8192 + 1024;  // + one partially used reservation per wave
+    if (!t.h_pair_cursor) {
+        HIP_TRY(hipHostMalloc((void **)&t.h_pair_cursor, 64, hipHostMallocDefault));
+        t.h_pair_cursor[0] = t.h_pair_cursor[1] = 0;
+        HIP_TRY(hipEventCreateWithFlags(&t.hint_ev, hipEventDisableTiming));
+    } else if (t.hint_reads && hipEventQuery(t.hint_ev) == hipSuccess) {
+        t.pairs_per_read = std::max(t.pairs_per_read, (double)t.h_pair_cursor[0] / (double)t.hint_reads);
+        if (t.hint_entry_cap) t.passes_hint = std::max<uint64_t>(1, (t.h_pair_cursor[1] + t.hint_entry_cap - 1) / t.hint_entry_cap);
+        t.hint_reads = 0;
+    }
+    (void)hipGetLastError();  // hipEventQuery reports "not ready" through the error state
+    // room for two candidates per read, or for 1.3 x what recent calls deferred (at most 24 per read: 40 B per slot);
+    // + one partially used reservation per wave.  Pairs that do not fit are certified inline (exact, slow).
+    const double per_read = std::min(24.0, std::max(2.0, 1.3 * t.pairs_per_read));
+    const uint64_t cap = (uint64_t)(per_read * (double)n_reads) + 32 * 8192 + 1024;
     HIP_TRY(t.d_pairs.ensure(cap));
     HIP_TRY(t.d_sorted.ensure(cap));
     HIP_TRY(t.d_fail.ensure(cap));
@@ -626,8 +645,11 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 if (tile_mode) {
                     // every read may survive with one candidate: (bases - (k-1) per read) * hashes * 1.125 + slack per bucket
                     const uint64_t max_chunks = nl + (a.pair_cap >> pfq::CHUNK_PAIRS_LOG2) + 2;
-                    uint64_t want = (uint64_t)((double)total_bytes * t.num_hashes * 1.13) + max_chunks * n_tiles * 544ull;
+                    uint64_t want = (uint64_t)((double)total_bytes * t.num_hashes * 1.13 * std::max(1.0, t.pairs_per_read)) +
+                                    max_chunks * n_tiles * 544ull;
                     if (want * 4 > tile_budget) want = tile_budget / 4;
+                    uint64_t forced_cap = 0;
+                    if (const char *e = getenv("PFQ_TILE_ENTRIES")) want = forced_cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // tests: force passes
                     hipError_t e1 = t.d_entries.ensure(want);
                     if (e1 != hipSuccess) {
                         (void)hipGetLastError();
@@ -658,7 +680,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         ta.flag_list = t.d_flag_list.p;
                         ta.flag_cap = (uint32_t)std::min<uint64_t>(t.d_flag_list.n, 0xffffffffu);
                         ta.entry_cursor = t.d_cursors.p + 2;
-                        ta.entry_cap = t.d_entries.n;
+                        ta.entry_cap = forced_cap ? std::min<uint64_t>(forced_cap, t.d_entries.n) : t.d_entries.n;
                         ta.entries = t.d_entries.p;
                         ta.gfill = t.d_gfill.p;
                         ta.fail = t.d_fail.p;
@@ -667,13 +689,29 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         if (const char *e = getenv("PFQ_BIN_BLOCKS")) bin_blocks = std::max(1, atoi(e));
                         if (const char *e = getenv("PFQ_TEST_BLOCKS")) test_blocks = std::max(1, atoi(e));
                         pfq::launch_tile_plan(ta, st);
-                        pfq::launch_tile_bin(ta, bin_blocks, st);
-                        if (ev) HIP_TRY(hipEventRecord(ev[3], st));
-                        pfq::launch_tile_test(ta, test_blocks, st);
+                        // The probe buckets of all pairs may exceed the buffer (reads that pass many leaves): the plan
+                        // spreads the chunks over passes that reuse it.  Their number is known on the device only; as
+                        // many passes as the previous call needed are launched without waiting, and chunks of later
+                        // passes (if any) are certified by the record kernel below — exact either way.
+                        const uint64_t n_passes = std::max<uint64_t>(1, t.passes_hint);
+                        for (uint64_t p = 0; p < n_passes; ++p) {
+                            ta.pass = (uint32_t)p;
+                            pfq::launch_tile_bin(ta, bin_blocks, st);
+                            if (p == 0 && ev) HIP_TRY(hipEventRecord(ev[3], st));
+                            pfq::launch_tile_test(ta, test_blocks, st);
+                        }
+                        v.pair_chunk = t.d_pair_chunk.p;
+                        v.chunks = t.d_chunks.p;
+                        v.entry_cursor = t.d_cursors.p + 2;
+                        v.entry_cap = ta.entry_cap;
+                        v.launched_passes = (uint32_t)n_passes;
+                        t.hint_entry_cap = ta.entry_cap;
+                        t.last_passes = (uint32_t)std::max<uint64_t>(n_passes, 1);
                         if (ev) HIP_TRY(hipEventRecord(ev[4], st));
                         v.only_flagged = 1;
                         v.n_flagged = ta.n_flagged;
                         v.flag_list = t.d_flag_list.p;
+                        v.flag_cap = ta.flag_cap;
                         t.last_tile_mode = 1;
                     }
                 }
@@ -682,6 +720,10 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                     HIP_TRY(hipEventRecord(ev[4], st));
                 }
                 pfq::launch_verify(v, vblocks, vthreads, st);
+                if (v.only_flagged == 1) {  // many flagged pairs (no room for their probe buckets): walk all pairs in leaf order instead
+                    v.only_flagged = 2;
+                    pfq::launch_verify(v, vblocks, vthreads, st);
+                }
                 if (ev) HIP_TRY(hipEventRecord(ev[5], st));
                 pfq::FinalizeArgs f{};
                 f.hp = t.hp;
@@ -705,6 +747,11 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
             }
             HIP_TRY(hipGetLastError());
+        }
+        if (bucketed) {  // how many pair slots this call used, for the next call's sizing
+            HIP_TRY(hipMemcpyAsync(t.h_pair_cursor, t.d_cursors.p + 1, 16, hipMemcpyDeviceToHost, st));  // pair cursor, bucket cursor
+            HIP_TRY(hipEventRecord(t.hint_ev, st));
+            t.hint_reads = n_reads;
         }
         if (!want_hits) return PFQ_OK;
         HIP_TRY(hipStreamSynchronize(st));
@@ -1233,6 +1280,8 @@ void pfq_tree_close(pfq_tree *tree) {
     if (!tree) return;
     (void)hipSetDevice(tree->device);
     (void)hipDeviceSynchronize();
+    if (tree->h_pair_cursor) (void)hipHostFree(tree->h_pair_cursor);
+    if (tree->hint_ev) (void)hipEventDestroy(tree->hint_ev);
     delete tree;
 }
 
@@ -1341,6 +1390,10 @@ int pfq_last_stats(pfq_tree *tree, pfq_stats *out) {
         out->n_chunks = (uint32_t)c[3];
         out->n_fallback_pairs = (uint32_t)(c[3] >> 32);
         out->tile_entries = c[2];
+        if (t.last_tile_mode && t.hint_entry_cap) {
+            out->tile_passes_launched = t.last_passes;
+            out->tile_passes_needed = (uint32_t)std::max<uint64_t>(1, (c[2] + t.hint_entry_cap - 1) / t.hint_entry_cap);
+        }
     }
     return PFQ_OK;
 }

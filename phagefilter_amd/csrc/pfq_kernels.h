@@ -51,6 +51,7 @@ struct QueryArgs {
                                  // first candidate is deferred (further candidates are certified inline)
 };
 
+struct ChunkDesc;
 struct VerifyArgs {
     HashParams hp;
     const uint8_t *seq;
@@ -65,7 +66,16 @@ struct VerifyArgs {
     uint32_t n_slices, slice_bits;
     unsigned int *queue;         // work cursors: [n_slices] (re-hash kernel) / [8 * n_sub] (record kernel)
     uint32_t n_sub;              // sub-queues per XCD (record kernel)
-    uint32_t only_flagged;       // 1: only pairs whose fail word has bit 1 set (fallback after the LDS-tile pass)
+    uint32_t only_flagged;       // fallback after the LDS-tile pass, pairs whose fail word has bit 1 set: 1 = from the compact
+                                 // list when they are few, 2 = by walking all sorted pairs when they are many
+    uint32_t flag_cap;           // entries of flag_list
+    // the tile passes are launched without waiting for the plan: chunks of passes >= launched_passes (their number
+    // was guessed from the previous call) are certified here as well (mode 2)
+    const uint32_t *pair_chunk;
+    const struct ChunkDesc *chunks;
+    const unsigned long long *entry_cursor;
+    uint64_t entry_cap;
+    uint32_t launched_passes;
     const unsigned int *n_flagged;  // number of such pairs (kernel returns at once when 0)
     const uint32_t *flag_list;      // their sorted-pair indices
     const uint4 *recs;           // probe records written by k_classify<DEFER> (nullptr: re-hash per slice)
@@ -104,9 +114,10 @@ struct ChunkDesc {
     uint32_t cap;      // entries per (chunk, tile) bucket; 0: no room, the chunk's pairs take the fallback
     uint64_t base;     // first entry of tile 0's bucket
     uint32_t leaf;
-    uint32_t pad;
+    uint32_t pass;     // the probe buckets are reused: chunks are binned and tested pass after pass
 };
 struct TileArgs {
+    uint32_t pass;               // k_tile_bin / k_tile_test: only the chunks of this pass
     HashParams hp;
     const uint64_t *bits;
     uint64_t n_words;
@@ -119,7 +130,7 @@ struct TileArgs {
     uint32_t *leaf_chunk0;       // [n_leaves + 1] first chunk of each leaf (chunks of a leaf are contiguous)
     uint32_t *pair_chunk;        // [pair_cap] chunk of each sorted pair
     unsigned int *n_chunks;      // counter
-    unsigned long long *entry_cursor;
+    unsigned long long *entry_cursor;  // virtual: pass = cursor / entry_cap, position in the pass = cursor % entry_cap
     uint64_t entry_cap;
     uint32_t *entries;
     unsigned int *gfill;         // [max_chunks * n_tiles]

@@ -808,9 +808,19 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs a) {
 __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
     __shared__ uint32_t s_item[2];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    if (a.only_flagged && *a.n_flagged == 0) return;  // the LDS-tile pass certified everything
-    // fallback mode: the work list is the compact list of flagged pairs, not all sorted pairs
-    const uint64_t n_pairs = a.only_flagged ? *a.n_flagged : *a.n_pairs_ptr;
+    // Fallback after the LDS-tile passes, two launches of which at most one works: few flagged pairs (bin or bucket
+    // overflows) are taken from the compact list (mode 1); many, or chunks whose pass was not launched, are found by
+    // walking all sorted pairs in leaf order and skipping the certified ones, which keeps the slices L2-resident (mode 2).
+    bool leftover = false;
+    if (a.only_flagged) {
+        const unsigned int nf = *a.n_flagged;
+        leftover = a.entry_cursor && *a.entry_cursor > (unsigned long long)a.launched_passes * a.entry_cap;
+        const bool many = (uint64_t)nf * 16u > (uint64_t)*a.n_pairs_ptr || nf > a.flag_cap;
+        const bool scan = many || leftover;
+        if (a.only_flagged == 1 ? (nf == 0 || scan) : !scan) return;
+    }
+    const bool from_list = a.only_flagged == 1, skip_certified = a.only_flagged == 2;
+    const uint64_t n_pairs = from_list ? *a.n_flagged : *a.n_pairs_ptr;
     // an item = (waves per block) x chunk consecutive pairs, pulled with ONE queue atomic (a same-address returning
     // atomic costs ~90 ns at the memory side, so items must be large) while the pairs in flight per XCD
     // (blocks per XCD x item) stay at about one leaf's share
@@ -819,12 +829,20 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
     const uint32_t home = xcc_id() & 7u, groups = 8u / a.n_slices;
     const uint32_t d = (uint32_t)a.hp.nbits, dw = d - (uint32_t)a.hp.w64, k = a.hp.k, nh = a.hp.num_hashes;
 
-    auto pair_index = [&](uint64_t i) -> uint32_t { return a.only_flagged ? a.flag_list[i] : (uint32_t)i; };
+    auto pair_index = [&](uint64_t i) -> uint32_t { return from_list ? a.flag_list[i] : (uint32_t)i; };
     auto load_meta = [&](uint64_t it, uint32_t &e_idx) -> uint4 {
         const uint64_t i = it * item_pairs + (uint64_t)wave * per_wave + lane;
-        const bool ok = it < n_items && lane < per_wave && i < n_pairs;
+        bool ok = it < n_items && lane < per_wave && i < n_pairs;
         e_idx = ok ? pair_index(i) : 0u;
-        return ok ? a.meta[e_idx] : make_uint4(0, 0, 0, 0);
+        if (ok && skip_certified && !(a.fail[e_idx] & 2u)) {  // certified by a tile pass ... if its pass was launched
+            bool pending = false;
+            if (leftover) {
+                const uint32_t c = a.pair_chunk[e_idx];
+                pending = c != 0xffffffffu && a.chunks[c].cap != 0 && a.chunks[c].pass >= a.launched_passes;
+            }
+            ok = pending;
+        }
+        return ok ? a.meta[e_idx] : make_uint4(0, 0, 0, 0);  // length 0 marks a pair to skip
     };
 
     // Every XCD's item sequence is dealt round-robin to n_sub sub-queues (own counter each) so that no counter
@@ -855,8 +873,10 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
             const uint64_t e0 = it_cur * item_pairs + (uint64_t)wave * per_wave;
             const uint32_t W = e0 >= n_pairs ? 0u : (uint32_t)(e0 + per_wave < n_pairs ? per_wave : n_pairs - e0);
             for (uint32_t j = 0; j < W; ++j) {
+                const uint32_t len_j = bcast_u32(meta_cur.z, j);
+                if (len_j == 0) continue;  // already certified (mode 2)
                 const uint64_t o0 = ((uint64_t)bcast_u32(meta_cur.y, j) << 32) | bcast_u32(meta_cur.x, j);
-                const uint64_t n = (uint64_t)bcast_u32(meta_cur.z, j) - k + 1;  // candidates always have n >= 1
+                const uint64_t n = (uint64_t)len_j - k + 1;  // candidates always have n >= 1
                 const uint4 *rp = a.recs + o0;
                 const uint32_t row = bcast_u32(meta_cur.w, j);
                 const uint32_t *bm = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)row * a.n_words);
@@ -965,15 +985,23 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
             unsigned long long mean = (s_sum * a.hp.num_hashes + a.n_tiles - 1) / a.n_tiles;
             uint32_t cap = (uint32_t)((mean + (mean >> 3) + 512 + 31) & ~31ull);
             unsigned long long need = (unsigned long long)cap * a.n_tiles;
-            unsigned long long base = atomicAdd(a.entry_cursor, need);
+            // The bucket space is virtual: position / entry_cap is the pass in which the chunk is binned and tested,
+            // position % entry_cap its place in the (reused) buffer.  A reservation that would straddle two passes is
+            // dropped and taken again (the cursor has moved past the boundary by then).
+            unsigned long long base = 0;
+            bool fits = need <= a.entry_cap;
+            while (fits) {
+                base = atomicAdd(a.entry_cursor, need);
+                if (base % a.entry_cap + need <= a.entry_cap) break;
+            }
             ChunkDesc dsc;
             dsc.row = a.meta[first].w;
             dsc.first = first;
             dsc.n = n;
-            dsc.cap = (base + need <= a.entry_cap) ? cap : 0u;
-            dsc.base = base;
+            dsc.cap = fits ? cap : 0u;   // a single chunk larger than the whole buffer: its pairs take the fallback
+            dsc.base = fits ? base % a.entry_cap : 0ull;
             dsc.leaf = c;
-            dsc.pad = 0;
+            dsc.pass = fits ? (uint32_t)(base / a.entry_cap) : 0u;
             a.chunks[chunk] = dsc;
         }
         __syncthreads();
@@ -1013,7 +1041,9 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
         const uint32_t e = rd * BIN_WAVES + wave;
         const bool have = rd < n_rounds && e < n_pairs;
         chunk = have ? a.pair_chunk[e] : NO_PAIR;
-        m = have ? a.meta[e] : make_uint4(0, 0, 0, 0);
+        // later passes know that there are several: drop the pairs of other passes before their records are requested
+        if (a.pass > 0 && chunk != NO_PAIR && (chunk == 0xffffffffu || a.chunks[chunk].pass != a.pass)) chunk = NO_PAIR;
+        m = (have && chunk != NO_PAIR) ? a.meta[e] : make_uint4(0, 0, 0, 0);
     };
     uint32_t nxt_chunk;
     uint4 nxt_meta;
@@ -1037,7 +1067,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
         }
         fetch(rd + gridDim.x, nxt_chunk, nxt_meta);
         if (my_chunk == 0xffffffffu) {  // chunk table full: fallback
-            if (lane == 0) flag_fallback(a, e);
+            if (lane == 0 && a.pass == 0) flag_fallback(a, e);
             my_chunk = NO_PAIR;
         }
         __syncthreads();
@@ -1057,9 +1087,10 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                 cached_id = cur;
             }
             __syncthreads();
+            if (dsc.cap != 0 && dsc.pass != a.pass) continue;  // binned in another pass (block-uniform; bins untouched)
             if (my_chunk == cur) {
                 if (dsc.cap == 0) {
-                    if (lane == 0) flag_fallback(a, e);  // no bucket space for this chunk
+                    if (lane == 0 && a.pass == 0) flag_fallback(a, e);  // no bucket space for this chunk
                 } else {
                     const uint32_t local = (e - dsc.first) << TILE_LOG2;
                     for (uint64_t g0 = 0; g0 < n; g0 += 3 * WIN_KMERS) {
@@ -1157,29 +1188,33 @@ __global__ void __launch_bounds__(512) k_tile_test(TileArgs a) {
         const uint32_t leaf = (uint32_t)(task / a.n_tiles), t = (uint32_t)(task % a.n_tiles);
         uint32_t ch = a.leaf_chunk0[leaf];
         if (ch == 0xffffffffu) continue;  // no pairs for this leaf
-        __syncthreads();
-        // the leaf's tile: words [t * tile_words, ...) of its filter row (zero beyond the filter's end)
-        const uint32_t row = ch < n_chunks ? a.chunks[ch].row : 0u;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)row * a.n_words);
-        const uint64_t w0 = (uint64_t)t * tile_words;
-        // filter rows are only 8-byte aligned: 8-byte loads, eight in flight per thread
-        for (uint32_t i0 = threadIdx.x * 2; i0 < tile_words; i0 += blockDim.x * 16) {
-            uint2 v[8];
-#pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) {
-                const uint32_t i = i0 + u * blockDim.x * 2;
-                v[u] = (i < tile_words && w0 + i + 1 < n_words32) ? *reinterpret_cast<const uint2 *>(src + w0 + i) : make_uint2(0, 0);
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) {
-                const uint32_t i = i0 + u * blockDim.x * 2;
-                if (i < tile_words) *reinterpret_cast<uint2 *>(s_tile + i) = v[u];
-            }
-        }
-        __syncthreads();
+        bool loaded = false;  // the tile is loaded when the first chunk of this pass is met (block-uniform)
         for (; ch < n_chunks && a.chunks[ch].leaf == leaf; ++ch) {
             const ChunkDesc dsc = a.chunks[ch];
-            if (!dsc.cap) continue;
+            if (!dsc.cap || dsc.pass != a.pass) continue;
+            if (!loaded) {
+                loaded = true;
+                __syncthreads();
+                // the leaf's tile: words [t * tile_words, ...) of its filter row (zero beyond the filter's end)
+                const uint32_t row = dsc.row;
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)row * a.n_words);
+                const uint64_t w0 = (uint64_t)t * tile_words;
+                // filter rows are only 8-byte aligned: 8-byte loads, eight in flight per thread
+                for (uint32_t i0 = threadIdx.x * 2; i0 < tile_words; i0 += blockDim.x * 16) {
+                    uint2 v[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; ++u) {
+                        const uint32_t i = i0 + u * blockDim.x * 2;
+                        v[u] = (i < tile_words && w0 + i + 1 < n_words32) ? *reinterpret_cast<const uint2 *>(src + w0 + i) : make_uint2(0, 0);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; ++u) {
+                        const uint32_t i = i0 + u * blockDim.x * 2;
+                        if (i < tile_words) *reinterpret_cast<uint2 *>(s_tile + i) = v[u];
+                    }
+                }
+                __syncthreads();
+            }
             uint32_t fill = a.gfill[(uint64_t)ch * a.n_tiles + t];
             if (fill > dsc.cap) fill = dsc.cap;
             const uint32_t *ent = a.entries + dsc.base + (uint64_t)t * dsc.cap;

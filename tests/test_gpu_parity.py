@@ -339,6 +339,31 @@ def test_config2_shape_64_leaves_k21(gpu):
     # every positive read hits (at least) its source leaf: about half of the reads
     assert 0.49 * n_reads < len(ohits) < 0.52 * n_reads
     gt.close()
+    # The probe buckets are reused pass after pass when they cannot hold all pairs.  The first call does not know how
+    # many passes the plan needs (one is launched, the record kernel certifies the chunks of the others); the next
+    # call launches as many as the previous one needed.  Same results every time.
+    want_counts = ot.leaf_counts()
+    for entries in (6_000_000, 60_000_000, 40_000):      # ~4 passes / 1 pass / chunks larger than the whole buffer
+        os.environ["PFQ_TILE_ENTRIES"] = str(entries)
+        try:
+            g2 = gpu_tree(genomes, ids, k, nbits, h, seeds=(0x0123456789ABCDEF, 0xFEDCBA9876543210))
+            g2.set_path(1)
+            seen = []
+            for call in range(3):
+                g2.reset_counts()
+                offs, leaves = g2.query_packed(seq, off, 1.0, want_hits=True)
+                assert g2.get_leaf_counts() == want_counts, (entries, call)
+                assert int(offs[-1]) == len(ohits)
+                st = g2.last_stats()
+                assert st.tile_mode == 1
+                seen.append((st.tile_passes_launched, st.tile_passes_needed, st.n_fallback_pairs))
+            if entries == 6_000_000:
+                assert seen[0][0] == 1 and seen[0][1] > 1 and seen[1][0] == seen[0][1] and seen[2][0] == seen[1][1], seen
+            if entries == 40_000:
+                assert all(s[2] > 0 for s in seen), seen   # every chunk takes the fallback
+            g2.close()
+        finally:
+            del os.environ["PFQ_TILE_ENTRIES"]
 
 
 # ---------------------------------------------------------------------------------------------------------------
