@@ -117,7 +117,9 @@ struct pfq_tree {
     DevBuf<uint2> d_hit_pairs, d_pairs, d_sorted;
     DevBuf<uint32_t> d_bucket, d_fail;  // bucket: cnt[n], off[n+1], cur[n]
     DevBuf<unsigned int> d_queue;
-    DevBuf<uint8_t> d_allhit, d_seq, d_miss;
+    DevBuf<uint8_t> d_allhit, d_seq;
+    DevBuf<unsigned long long> d_miss_words;  // thresholds < 1: k-mer miss bits of every deferred pair
+    DevBuf<uint32_t> d_miss_pos, d_bucket_w;  // first word per sorted pair; per-bucket word counts / offsets / cursors
     DevBuf<uint32_t> d_long;
     DevBuf<uint4> d_recs;  // probe records of the bucketed path (16 B per read byte)
     DevBuf<uint4> d_meta;  // resolved per-pair metadata for the record-driven verify
@@ -583,13 +585,22 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 }
                 a.recs = recs;
                 a.rec_cap = recs ? t.d_recs.n : 0;
-                // thresholds < 1: slices report per-k-mer misses in a byte array indexed like the records
-                uint8_t *miss = nullptr;
+                // thresholds < 1: every deferred pair owns ceil(n/64) words of k-mer miss bits that the slices OR into
+                uint32_t *cntw = nullptr, *offw = nullptr, *curw = nullptr;
                 if (counts_mode) {
-                    HIP_TRY(t.d_miss.ensure(total_bytes + 64));
-                    HIP_TRY(hipMemsetAsync(t.d_miss.p, 0, total_bytes + 64, st));
-                    miss = t.d_miss.p;
-                    a.one_pair_per_read = 1;
+                    const uint64_t avg_len = n_reads ? total_bytes / n_reads : 0;
+                    const uint64_t miss_cap = std::min<uint64_t>(a.pair_cap * ((avg_len >> 6) + 2) + 8192ull * 1024ull, 0xfffffff0ull);
+                    HIP_TRY(t.d_miss_words.ensure(miss_cap));
+                    HIP_TRY(t.d_miss_pos.ensure(t.d_pairs.n));
+                    HIP_TRY(t.d_bucket_w.ensure(3 * nb + 2));
+                    cntw = t.d_bucket_w.p;
+                    offw = cntw + nb;
+                    curw = offw + nb + 1;
+                    HIP_TRY(hipMemsetAsync(t.d_miss_words.p, 0, miss_cap * 8, st));
+                    HIP_TRY(hipMemsetAsync(cntw, 0, nb * 4, st));
+                    a.bucket_words = cntw;
+                    a.miss_cursor = t.d_cursors.p + 5;
+                    a.miss_cap = miss_cap;
                 }
                 uint32_t n_slices = 1;
                 uint64_t slice_target = SLICE_TARGET_BYTES;
@@ -604,8 +615,10 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 if (a.batch_tails) pfq::launch_tail_records(a, 2048, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
                 pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nb, st);
+                if (counts_mode) pfq::launch_bucket_scan(cntw, offw, curw, (uint32_t)nb, st);
                 pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, sub_log2, t.d_sorted.p,
-                                           recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, 1024, st);
+                                           recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, offw, curw,
+                                           counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size, 1024, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[2], st));
                 pfq::VerifyArgs v{};
                 v.hp = t.hp;
@@ -618,7 +631,8 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 v.n_pairs_ptr = off + nb;
                 v.fail = t.d_fail.p;
                 v.recs = recs;
-                v.miss = miss;
+                v.miss_words = counts_mode ? t.d_miss_words.p : nullptr;
+                v.miss_pos = counts_mode ? t.d_miss_pos.p : nullptr;
                 v.meta = t.d_meta.p;
                 v.n_slices = n_slices;
                 uint64_t sb = (t.n_words * 64 + n_slices - 1) / n_slices;
@@ -732,7 +746,8 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 f.bucket_off = off;
                 f.sub_log2 = sub_log2;
                 f.fail = t.d_fail.p;
-                f.miss = miss;
+                f.miss_words = v.miss_words;
+                f.miss_pos = v.miss_pos;
                 f.threshold = threshold;
                 f.n_leaves = (uint32_t)nl;
                 f.counts = t.d_counts.p;

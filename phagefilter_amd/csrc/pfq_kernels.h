@@ -47,8 +47,11 @@ struct QueryArgs {
     uint32_t *long_list;         // thresholds < 1: reads of >= 256 k-mers, classified by a second launch (wider counters)
     unsigned int *n_long;
     uint32_t batch_tails;        // theta == 1 with records: last windows of <= TAIL_KMERS k-mers are left to k_tail_records
-    uint32_t one_pair_per_read;  // thresholds < 1: the per-k-mer miss bytes are indexed by read, so only a read's
-                                 // first candidate is deferred (further candidates are certified inline)
+    // thresholds < 1: every deferred pair owns ceil(n/64) u64 words of k-mer miss bits.  k_classify only accounts for
+    // them (per bucket, and against the buffer's capacity through per-wave reservations); k_bucket_scatter places them.
+    uint32_t *bucket_words;            // [n_leaves << sub_log2] miss words per bucket, or nullptr (threshold 1)
+    unsigned long long *miss_cursor;   // words reserved so far
+    uint64_t miss_cap;                 // words in the buffer
 };
 
 struct ChunkDesc;
@@ -79,8 +82,8 @@ struct VerifyArgs {
     const unsigned int *n_flagged;  // number of such pairs (kernel returns at once when 0)
     const uint32_t *flag_list;      // their sorted-pair indices
     const uint4 *recs;           // probe records written by k_classify<DEFER> (nullptr: re-hash per slice)
-    uint8_t *miss;               // thresholds < 1: miss[read byte offset + k-mer] = 1 when a probed bit of that k-mer is 0
-                                 // (nullptr at threshold 1: any miss fails the pair)
+    unsigned long long *miss_words;  // thresholds < 1: bit q of the pair's words = a probed bit of its k-mer q is 0
+    const uint32_t *miss_pos;        // [sorted pair] first word of the pair (nullptr at threshold 1: any miss fails the pair)
     uint32_t chunk;
 };
 
@@ -91,7 +94,8 @@ struct FinalizeArgs {
     const uint32_t *bucket_off;  // [(n_leaves << sub_log2) + 1]
     uint32_t sub_log2;
     const uint32_t *fail;
-    const uint8_t *miss;         // thresholds < 1 (see VerifyArgs); nullptr at threshold 1
+    const unsigned long long *miss_words;  // thresholds < 1 (see VerifyArgs); nullptr at threshold 1
+    const uint32_t *miss_pos;
     float threshold;
     uint32_t n_leaves;
     unsigned long long *counts;
@@ -148,9 +152,11 @@ void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st);
 void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int blocks, hipStream_t st);
 void launch_tail_records(const QueryArgs &a, int blocks, hipStream_t st);  // after launch_classify when a.batch_tails
 void launch_bucket_scan(const uint32_t *bucket_cnt, uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t n, hipStream_t st);
+// words_off / words_cur / miss_pos: thresholds < 1 (miss words of a bucket start at words_off[bucket]); else nullptr
 void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
                            const uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t sub_log2, uint2 *sorted, uint4 *meta,
-                           const uint64_t *read_off, const uint32_t *col_row, int blocks, hipStream_t st);
+                           const uint64_t *read_off, const uint32_t *col_row, const uint32_t *words_off, uint32_t *words_cur,
+                           uint32_t *miss_pos, uint32_t kmer_size, int blocks, hipStream_t st);
 void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st);
 void launch_finalize(const FinalizeArgs &a, hipStream_t st);
 

@@ -448,6 +448,7 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
     // cursor per chunk (a single hot address saturates at ~88 atomics/us); unused slots are voided at the end
     unsigned long long pair_base = 0;
     uint32_t pair_used = PAIR_CHUNK;
+    uint32_t miss_left = 0;  // thresholds < 1: miss words this wave may still hand out (reserved 1024 at a time)
 
     auto process_read = [&](uint64_t r, const uint32_t *pre) {  // pre: frontier words from the dense counting screen
         const uint64_t o0 = a.off[r], L = a.off[r + 1] - o0;
@@ -492,7 +493,16 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             uint32_t col = (uint32_t)src * 32u + bit;
             if ((int)lane == src) live &= ~(1u << bit);
             ++st_cand;
-            if (DEFER && (!a.recs || o0 + rc.n <= a.rec_cap) && !(a.one_pair_per_read && prepared)) {
+            // (reads of >= 2^37 k-mers cannot be deferred: 0xffffffff words are never available)
+            const uint32_t miss_need = (COUNTS && a.bucket_words) ? (rc.n < (1ull << 37) ? (uint32_t)((rc.n + 63) >> 6) : 0xffffffffu) : 0u;
+            if (DEFER && COUNTS && a.bucket_words && miss_left < miss_need && miss_need != 0xffffffffu) {  // wave-uniform
+                const uint32_t want = miss_need > 1024u ? miss_need : 1024u;
+                unsigned long long got = 0;
+                if (lane == 0) got = atomicAdd(a.miss_cursor, (unsigned long long)want);
+                got = ((unsigned long long)bcast_u32((uint32_t)(got >> 32), 0) << 32) | bcast_u32((uint32_t)got, 0);
+                if (got + want <= a.miss_cap) miss_left = want;  // else: no room, this pair is certified inline
+            }
+            if (DEFER && (!a.recs || o0 + rc.n <= a.rec_cap) && miss_left >= miss_need) {
                 if (pair_used == PAIR_CHUNK) {  // wave-uniform
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(a.pair_cursor, (unsigned long long)PAIR_CHUNK);
@@ -504,9 +514,12 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
                 }
                 if (pair_used < PAIR_CHUNK) {
                     if (lane == 0) {
+                        const uint32_t bkt = (col << a.sub_log2) | ((uint32_t)r & ((1u << a.sub_log2) - 1u));
                         a.pairs[pair_base + pair_used] = make_uint2((uint32_t)r, col);
-                        atomicAdd(&a.bucket_cnt[(col << a.sub_log2) | ((uint32_t)r & ((1u << a.sub_log2) - 1u))], 1u);
+                        atomicAdd(&a.bucket_cnt[bkt], 1u);
+                        if (COUNTS && a.bucket_words) atomicAdd(&a.bucket_words[bkt], miss_need);
                     }
+                    miss_left -= miss_need;
                     ++pair_used;
                     ++st_def;
                     if (a.recs && !prepared) {  // hash the read once; every slice of the verify reuses the records
@@ -719,7 +732,8 @@ void launch_bucket_scan(const uint32_t *bucket_cnt, uint32_t *bucket_off, uint32
 __global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr,
                                                         uint64_t pair_cap, const uint32_t *off, uint32_t *cur, uint32_t sub_log2,
                                                         uint2 *sorted, uint4 *meta, const uint64_t *read_off,
-                                                        const uint32_t *col_row) {
+                                                        const uint32_t *col_row, const uint32_t *words_off,
+                                                        uint32_t *words_cur, uint32_t *miss_pos, uint32_t kmer_size) {
     uint64_t n = *n_pairs_ptr;
     if (n > pair_cap) n = pair_cap;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -731,14 +745,19 @@ __global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, cons
         if (meta) {
             uint64_t o0 = read_off[p.x], L = read_off[p.x + 1] - o0;
             meta[pos] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)L, col_row[p.y]);
+            if (miss_pos) {  // thresholds < 1: the pair's miss words, ceil(n/64) of them, inside its bucket's range
+                const uint32_t words = (uint32_t)((L - kmer_size + 1 + 63) >> 6);
+                miss_pos[pos] = words_off[bkt] + atomicAdd(&words_cur[bkt], words);
+            }
         }
     }
 }
 void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
                            const uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t sub_log2, uint2 *sorted, uint4 *meta,
-                           const uint64_t *read_off, const uint32_t *col_row, int blocks, hipStream_t st) {
+                           const uint64_t *read_off, const uint32_t *col_row, const uint32_t *words_off, uint32_t *words_cur,
+                           uint32_t *miss_pos, uint32_t kmer_size, int blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, pairs, n_pairs_ptr, pair_cap, bucket_off, bucket_cur,
-                       sub_log2, sorted, meta, read_off, col_row);
+                       sub_log2, sorted, meta, read_off, col_row, words_off, words_cur, miss_pos, kmer_size);
 }
 
 // ---- K2 for bucketed survivors: L2-resident filter slices ------------------------------------------------------------
@@ -927,10 +946,13 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
 #pragma unroll
                         for (int u = 0; u < 6; ++u) okw[u / 2] &= vv[u] >> (ix[u] & 31u);
                     }
-                    if (a.miss) {  // thresholds < 1: record which k-mers are not contained (idempotent byte stores)
+                    if (a.miss_words) {  // thresholds < 1: record which k-mers are not contained (OR: a k-mer can miss in several slices)
+                        const uint32_t mp = a.miss_pos[bcast_u32(idx_cur, j)];
 #pragma unroll
-                        for (int w = 0; w < 3; ++w)
-                            if (valid[w] && !(okw[w] & 1u)) a.miss[o0 + g0 + 64u * w + lane] = 1;
+                        for (int w = 0; w < 3; ++w) {
+                            const uint64_t mm = ballot64(valid[w] && !(okw[w] & 1u));
+                            if (mm && lane == 0) atomicOr(&a.miss_words[mp + (uint32_t)(g0 >> 6) + (uint32_t)w], (unsigned long long)mm);
+                        }
                     } else {
                         miss = miss || !(okw[0] & okw[1] & okw[2] & 1u);
                     }
@@ -1041,9 +1063,9 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
         const uint32_t e = rd * BIN_WAVES + wave;
         const bool have = rd < n_rounds && e < n_pairs;
         chunk = have ? a.pair_chunk[e] : NO_PAIR;
+        m = have ? a.meta[e] : make_uint4(0, 0, 0, 0);  // (independent of the chunk load: both are in flight together)
         // later passes know that there are several: drop the pairs of other passes before their records are requested
         if (a.pass > 0 && chunk != NO_PAIR && (chunk == 0xffffffffu || a.chunks[chunk].pass != a.pass)) chunk = NO_PAIR;
-        m = (have && chunk != NO_PAIR) ? a.meta[e] : make_uint4(0, 0, 0, 0);
     };
     uint32_t nxt_chunk;
     uint4 nxt_meta;
@@ -1261,19 +1283,12 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
             const uint64_t o0 = a.off[p.x], L = a.off[p.x + 1] - o0, n = L - a.hp.k + 1;
             uint64_t need = n;
             bool pass;
-            if (a.miss) {  // thresholds < 1: contained k-mers = n - missing ones; query_passes (query.rs:38-49)
-                // miss bytes are 0/1: sum them as popcounts of the aligned 8-byte words covering [o0, o0+n)
-                const uint64_t lo = o0 & ~7ull, end = o0 + n;
-                const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(a.miss + lo);
-                const uint32_t nw = (uint32_t)(((end + 7ull) & ~7ull) - lo) >> 3;
+            if (a.miss_words) {  // thresholds < 1: contained k-mers = n - missing ones; query_passes (query.rs:38-49)
+                const unsigned long long *mw = a.miss_words + a.miss_pos[e];
+                const uint32_t nw = (uint32_t)((n + 63) >> 6);
                 uint64_t missing = 0;
 #pragma unroll 4
-                for (uint32_t w = 0; w < nw; ++w) {
-                    unsigned long long v = mw[w];
-                    if (w == 0) v &= ~0ull << (8u * (uint32_t)(o0 & 7ull));
-                    if (w == nw - 1u && (end & 7ull)) v &= (1ull << (8u * (uint32_t)(end & 7ull))) - 1ull;
-                    missing += (uint64_t)__popcll(v);
-                }
+                for (uint32_t w = 0; w < nw; ++w) missing += (uint64_t)__popcll(mw[w]);
                 need = need_kmers(a.threshold, n);
                 pass = n - missing >= need;
             } else pass = !(a.fail[e] & 1u);
