@@ -91,7 +91,7 @@ struct pfq_tree {
     unsigned long long *h_pair_cursor = nullptr;
     hipEvent_t hint_ev = nullptr;
     uint64_t hint_reads = 0, hint_entry_cap = 0, passes_hint = 1;
-    double pairs_per_read = 1.0;
+    double pairs_per_read = 1.0, hits_per_read = 1.0;
     bool topology_dirty = false;       // nodes appended by pfq_tree_insert: renumber + verify before the next use
     uint64_t internal_counter = 0;     // names of internal nodes created by pfq_tree_insert
     size_t n_rows = 0, row_capacity = 0;  // filter rows in use / allocated in d_bits
@@ -465,7 +465,8 @@ int build_layout(pfq_tree &t) {
 int ensure_scratch(pfq_tree &t, uint64_t n_reads, bool want_hits) {
     HIP_TRY(t.d_stats.ensure(pfq::ST_N));
     HIP_TRY(t.d_cursors.ensure(8));
-    const uint64_t cap = 2 * n_reads + 1024;
+    // two hits per read, or 1.3 x what recent blocks reported (a block that overflows is run again, see query_device)
+    const uint64_t cap = (uint64_t)(std::max(2.0, 1.3 * t.hits_per_read) * (double)n_reads) + 1024;
     if (want_hits) {
         HIP_TRY(t.d_hit_pairs.ensure(cap));
         HIP_TRY(t.d_allhit.ensure(n_reads + 1));
@@ -772,6 +773,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
         HIP_TRY(hipStreamSynchronize(st));
         unsigned long long cursors[2] = {0, 0};
         HIP_TRY(hipMemcpy(cursors, t.d_cursors.p, 16, hipMemcpyDeviceToHost));
+        if (n_reads) t.hits_per_read = std::max(t.hits_per_read, (double)cursors[0] / (double)n_reads);
         if (cursors[0] <= hit_cap) {
             // CSR read -> leaves (ascending), all-hit reads expand to every leaf
             std::vector<uint2> pairs((size_t)cursors[0]);
