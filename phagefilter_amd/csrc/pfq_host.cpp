@@ -517,7 +517,8 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     uint64_t rec_budget = 64ull << 30;
     if (const char *e = getenv("PFQ_RECORD_GB")) rec_budget = strtoull(e, nullptr, 10) << 30;
     const bool recs_possible = total_bytes && t.nbits < (1ull << 30) && t.num_hashes <= 35 && total_bytes * 16 <= rec_budget;
-    bool bucketed = (t.force_path == 1) || (t.force_path < 0 && n_reads >= BUCKET_MIN_READS);
+    // (or as many bases as 2^18 reads of 150 bp: long reads bring the same certificate work with fewer reads)
+    bool bucketed = (t.force_path == 1) || (t.force_path < 0 && (n_reads >= BUCKET_MIN_READS || total_bytes >= BUCKET_MIN_READS * 150));
     if (!(thr_one || (thr_frac && recs_possible)) || !t.guard_col.empty() || nl == 0) bucketed = false;
     if (bucketed) PFQ_TRY(ensure_bucket_scratch(t, n_reads));
     t.last_path = bucketed ? 1 : 0;

@@ -1048,7 +1048,7 @@ template <uint32_t BIN_WAVES, uint32_t BIN_CAP>
 __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
     constexpr uint32_t BIN_STRIDE = BIN_CAP + 1;
     extern __shared__ uint32_t s_dyn[];   // cnt[MAX_TILES] then bins[n_tiles][BIN_CAP]
-    __shared__ uint32_t s_wc[BIN_WAVES];
+    __shared__ uint32_t s_wc[BIN_WAVES], s_n[BIN_WAVES];
     __shared__ uint32_t s_pos[MAX_TILES];
     uint32_t *cnt = s_dyn, *bins = s_dyn + MAX_TILES;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -1093,16 +1093,19 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
             my_chunk = NO_PAIR;
         }
         __syncthreads();
-        if (lane == 0) s_wc[wave] = my_chunk;
+        if (lane == 0) {
+            s_wc[wave] = my_chunk;
+            s_n[wave] = my_chunk == NO_PAIR ? 0u : (uint32_t)(n < 0xffffffffull ? n : 0xffffffffull);
+        }
         __syncthreads();
-        uint32_t pending = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < BIN_WAVES; ++w) pending |= (s_wc[w] != NO_PAIR ? 1u : 0u) << w;
+        // lane w of every wave holds wave w's chunk and k-mer count: the per-chunk bookkeeping below is ballots and
+        // a 16-lane reduction instead of 2 x BIN_WAVES LDS reads per thread
+        const uint32_t c_l = lane < BIN_WAVES ? s_wc[lane] : NO_PAIR, n_l = lane < BIN_WAVES ? s_n[lane] : 0u;
+        uint32_t pending = (uint32_t)ballot64(c_l != NO_PAIR);
         while (pending) {
-            const uint32_t cur = s_wc[__ffs((int)pending) - 1];
-#pragma unroll
-            for (uint32_t w = 0; w < BIN_WAVES; ++w)
-                if (s_wc[w] == cur) pending &= ~(1u << w);
+            const uint32_t cur = bcast_u32(c_l, __ffs((int)pending) - 1);
+            const uint32_t here = (uint32_t)ballot64(c_l == cur);
+            pending &= ~here;
             for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) cnt[t] = 0;
             if (cur != cached_id) {  // block-uniform
                 dsc = a.chunks[cur];
@@ -1110,56 +1113,73 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
             }
             __syncthreads();
             if (dsc.cap != 0 && dsc.pass != a.pass) continue;  // binned in another pass (block-uniform; bins untouched)
-            if (my_chunk == cur) {
-                if (dsc.cap == 0) {
-                    if (lane == 0 && a.pass == 0) flag_fallback(a, e);  // no bucket space for this chunk
-                } else {
-                    const uint32_t local = (e - dsc.first) << TILE_LOG2;
-                    for (uint64_t g0 = 0; g0 < n; g0 += 3 * WIN_KMERS) {
-                        uint4 rec[3];
-                        bool valid[3];
+            // The bins hold BIN_CAP entries per tile between two flushes: the k-mers of this chunk's pairs are binned
+            // in n_seg segments so that a segment brings about 0.75 * BIN_CAP probes per tile (one segment for reads
+            // of up to ~160 k-mers; long reads take several).  n_seg is block-uniform, segment lengths are per wave.
+            uint32_t sum_n = (c_l == cur) ? n_l : 0u, max_n = sum_n;  // (k-mer counts of a round stay far below 2^32)
+            for (int sft = 1; sft < (int)BIN_WAVES; sft <<= 1) {
+                sum_n += (uint32_t)__shfl_xor((int)sum_n, sft);
+                const uint32_t o = (uint32_t)__shfl_xor((int)max_n, sft);
+                max_n = o > max_n ? o : max_n;
+            }
+            const uint64_t kmers_here = bcast_u32(sum_n, 0);
+            max_n = bcast_u32(max_n, 0);
+            const uint32_t waves_here = (uint32_t)__popc(here);
+            const uint64_t seg_target = (uint64_t)(BIN_CAP - BIN_CAP / 4) * a.n_tiles;
+            // everything at once if it fits; else windows of whole 64-k-mer multiples per wave and segment
+            uint64_t seg_len = ~0ull;
+            uint32_t n_seg = 1;
+            if (dsc.cap && kmers_here * nh > seg_target) {
+                seg_len = (seg_target / ((uint64_t)waves_here * nh)) & ~(uint64_t)(WIN_KMERS - 1);
+                if (seg_len < WIN_KMERS) seg_len = WIN_KMERS;
+                n_seg = (uint32_t)((max_n + seg_len - 1) / seg_len);
+            }
+            // bins the k-mers [lo, hi) of my pair (whole 64-k-mer windows from lo on)
+            auto bin_range = [&](const uint64_t lo_k, const uint64_t hi_k) {
+                const uint32_t local = (e - dsc.first) << TILE_LOG2;
+                for (uint64_t g0 = lo_k; g0 < hi_k; g0 += 3 * WIN_KMERS) {
+                    uint4 rec[3];
+                    bool valid[3];
 #pragma unroll
-                        for (int w = 0; w < 3; ++w) {
-                            if (g0 == 0) {
-                                rec[w] = rec0[w];
-                                valid[w] = valid0[w];
-                            } else {
-                                const uint64_t q = g0 + 64u * w + lane;
-                                valid[w] = q < n;
-                                rec[w] = valid[w] ? rp[q] : make_uint4(0, 0, 0, 0);
-                            }
-                        }
-                        // branch-free append (an overflowing bin keeps overwriting its last slot and is detected at
-                        // flush time, cnt > BIN_CAP, when the round's pairs are sent to the fallback); the three
-                        // windows advance together so three LDS atomics are in flight per step
-                        RecordIter rit[3];
-#pragma unroll
-                        for (int w = 0; w < 3; ++w) rit[w].init(rec[w]);
-                        auto put3 = [&](uint32_t i0, uint32_t i1, uint32_t i2) {
-                            const uint32_t ix[3] = {i0, i1, i2};
-                            uint32_t tile[3], slot[3];
-#pragma unroll
-                            for (int w = 0; w < 3; ++w) tile[w] = ix[w] >> TILE_LOG2;
-#pragma unroll
-                            for (int w = 0; w < 3; ++w) slot[w] = valid[w] ? atomicAdd(&cnt[tile[w]], 1u) : 0u;
-#pragma unroll
-                            for (int w = 0; w < 3; ++w)
-                                if (valid[w]) bins[tile[w] * BIN_STRIDE + min(slot[w], BIN_CAP - 1u)] = local | (ix[w] & ((1u << TILE_LOG2) - 1u));
-                        };
-                        put3(rit[0].i0, rit[1].i0, rit[2].i0);
-                        if (nh > 1) put3(rit[0].g, rit[1].g, rit[2].g);
-                        if (nh > 2) put3(rit[0].x, rit[1].x, rit[2].x);
-                        for (uint32_t i = 3; i < nh; ++i) {
-                            const uint32_t s0 = rit[0].step(d, dw), s1 = rit[1].step(d, dw), s2 = rit[2].step(d, dw);
-                            put3(s0, s1, s2);
+                    for (int w = 0; w < 3; ++w) {
+                        const uint64_t q = g0 + 64u * w + lane;
+                        if (g0 == 0) {
+                            rec[w] = rec0[w];
+                            valid[w] = valid0[w] && q < hi_k;
+                        } else {
+                            valid[w] = q < hi_k;
+                            rec[w] = valid[w] ? rp[q] : make_uint4(0, 0, 0, 0);
                         }
                     }
+                    // branch-free append (an overflowing bin keeps overwriting its last slot and is detected at
+                    // flush time, cnt > BIN_CAP, when the round's pairs are sent to the fallback); the three
+                    // windows advance together so three LDS atomics are in flight per step
+                    RecordIter rit[3];
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) rit[w].init(rec[w]);
+                    auto put3 = [&](uint32_t i0, uint32_t i1, uint32_t i2) {
+                        const uint32_t ix[3] = {i0, i1, i2};
+                        uint32_t tile[3], slot[3];
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) tile[w] = ix[w] >> TILE_LOG2;
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) slot[w] = valid[w] ? atomicAdd(&cnt[tile[w]], 1u) : 0u;
+#pragma unroll
+                        for (int w = 0; w < 3; ++w)
+                            if (valid[w]) bins[tile[w] * BIN_STRIDE + min(slot[w], BIN_CAP - 1u)] = local | (ix[w] & ((1u << TILE_LOG2) - 1u));
+                    };
+                    put3(rit[0].i0, rit[1].i0, rit[2].i0);
+                    if (nh > 1) put3(rit[0].g, rit[1].g, rit[2].g);
+                    if (nh > 2) put3(rit[0].x, rit[1].x, rit[2].x);
+                    for (uint32_t i = 3; i < nh; ++i) {
+                        const uint32_t s0 = rit[0].step(d, dw), s1 = rit[1].step(d, dw), s2 = rit[2].step(d, dw);
+                        put3(s0, s1, s2);
+                    }
                 }
-            }
-            __syncthreads();
+            };
             // flush: every tile's bin goes to its (chunk, tile) bucket as one run; all reservations of the round
             // are made by one atomic instruction (one lane per tile), not tile after tile
-            if (dsc.cap) {
+            auto flush = [&]() {
                 bool over = false;
                 for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) {
                     over = over || cnt[t] > BIN_CAP;
@@ -1178,6 +1198,25 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                     } else {  // bucket full: the pairs whose probes are dropped take the fallback
                         for (uint32_t i = lane; i < c; i += 64) flag_fallback(a, dsc.first + (bins[t * BIN_STRIDE + i] >> TILE_LOG2));
                     }
+                }
+            };
+            if (dsc.cap == 0) {  // no bucket space for this chunk
+                if (my_chunk == cur && lane == 0 && a.pass == 0) flag_fallback(a, e);
+            } else if (n_seg == 1) {  // the common case, kept free of the segment arithmetic
+                if (my_chunk == cur) bin_range(0, n);
+                __syncthreads();
+                flush();
+            } else {
+                for (uint32_t seg = 0; seg < n_seg; ++seg) {
+                    if (seg) {
+                        for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) cnt[t] = 0;
+                        __syncthreads();
+                    }
+                    const uint64_t lo_k = (uint64_t)seg * seg_len;
+                    if (my_chunk == cur && lo_k < n) bin_range(lo_k, lo_k + seg_len < n ? lo_k + seg_len : n);
+                    __syncthreads();
+                    flush();
+                    __syncthreads();
                 }
             }
             __syncthreads();
