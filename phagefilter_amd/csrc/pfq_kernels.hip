@@ -287,26 +287,29 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
 // Here a wave screens 64/lpr consecutive reads at once, lpr = rw/4 lanes per read: lane (j, q) hashes k-mer
 // pos+q of read j and owns dwords 4q..4q+3 (128 leaf columns) of every row of that read, so the vertical counters
 // never cross lanes; each pass issues lpr row gathers of 16 bytes per lane before any is consumed.  Needs
-// 16 <= rw <= 64 and reads of fewer than SHORT_KMERS k-mers; other reads are returned in `irregular` for the
-// per-read path.  On return live_out[j*rw + w] holds the frontier words of read j and `survive` the reads with a
-// non-empty frontier.
+// 16 <= rw <= 64 and reads of fewer than 2^P k-mers (P counter planes: 8 in the main launch, 16 in the launch for
+// long reads); other reads are returned in `irregular` for the per-read path.  The group is reads r0 .. r0+n-1, or
+// list[r0 .. r0+n-1] when a list is given; `rid` returns the lane's read.  On return live_out[j*rw + w] holds the
+// frontier words of read j and `survive` the reads with a non-empty frontier.
+template <uint32_t P>
 __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const uint8_t *comp, uint32_t *live_out,
-                                             const QueryArgs &a, uint64_t r0, uint32_t n_in_group, uint32_t &survive,
-                                             uint32_t &irregular, uint64_t &lane_len) {
-    constexpr uint32_t P = 8;
+                                             const QueryArgs &a, const uint32_t *list, uint64_t r0, uint32_t n_in_group,
+                                             uint32_t &survive, uint32_t &irregular, uint64_t &lane_len, uint64_t &rid) {
     const uint32_t lane = lane_id(), k = a.hp.k, rw = a.rw;
     const uint32_t lpr_log2 = a.rw_log2 - 2u, lpr = 1u << lpr_log2, rpw = 64u >> lpr_log2;
     const uint32_t j = lane >> lpr_log2, q = lane & (lpr - 1u);
     uint64_t o0 = 0, L = 0;
+    rid = 0;
     if (j < n_in_group) {
-        o0 = a.off[r0 + j];
-        L = a.off[r0 + j + 1] - o0;
+        rid = list ? (uint64_t)list[r0 + j] : r0 + j;
+        o0 = a.off[rid];
+        L = a.off[rid + 1] - o0;
     }
     lane_len = (q == 0) ? L : 0;
     const uint64_t n64 = (L >= k) ? (L - k + 1) : 0;
     const uint64_t need = need_kmers(a.threshold, n64);
     const bool in_group = j < n_in_group;
-    const bool regular = in_group && n64 >= 1 && n64 < SHORT_KMERS && need >= 1 && need <= n64;
+    const bool regular = in_group && n64 >= 1 && n64 < (1ull << P) && need >= 1 && need <= n64;
     const uint32_t n = regular ? (uint32_t)n64 : 0u, maxmiss = regular ? (uint32_t)(n64 - need) : 0u;
     irregular = 0;
     {
@@ -433,7 +436,7 @@ __device__ __forceinline__ bool has_batched_tail(uint64_t n) {
 template <bool DEFER, bool COUNTS, bool LONG = false>
 __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
     __shared__ BlockLds lds;
-    __shared__ DenseLds<DEFER ? !LONG : (COUNTS && !LONG)> dlds;
+    __shared__ DenseLds<(DEFER && !LONG) || COUNTS> dlds;
     fill_complement(lds.comp);
     __syncthreads();
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -591,10 +594,10 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
         for (uint64_t g = gw; g < n_groups; g += nw) {
             const uint64_t r0 = g * rpw;
             const uint32_t cnt = (uint32_t)(a.n_reads - r0 < rpw ? a.n_reads - r0 : rpw);
-            uint64_t lane_len;
+            uint64_t lane_len, rid;
             uint32_t survive, irregular;
-            dense_counts(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, r0, cnt, survive, irregular,
-                         lane_len);
+            dense_counts<8>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, nullptr, r0, cnt, survive,
+                            irregular, lane_len, rid);
             if (!(((survive | irregular) >> (lane >> (a.rw_log2 - 2u))) & 1u)) dense_bytes += lane_len;
             while (survive) {
                 const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
@@ -605,6 +608,30 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
                 const uint32_t jj = (uint32_t)__ffs((int)irregular) - 1u;
                 irregular &= irregular - 1u;
                 process_read(r0 + jj, nullptr);
+            }
+        }
+    } else if (COUNTS && LONG && a.rw >= 16u && a.ones_row != 0u) {
+        // the reads of >= 256 k-mers queued by the first launch: the same dense screen with 16 counter planes
+        const uint32_t rpw = 256u >> a.rw_log2, lpr_log2 = a.rw_log2 - 2u;
+        const uint64_t n_long = *a.n_long, n_groups = (n_long + rpw - 1) / rpw;
+        for (uint64_t g = gw; g < n_groups; g += nw) {
+            const uint64_t r0 = g * rpw;
+            const uint32_t cnt = (uint32_t)(n_long - r0 < rpw ? n_long - r0 : rpw);
+            uint64_t lane_len, rid;
+            uint32_t survive, irregular;
+            dense_counts<NPLANES>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, a.long_list, r0, cnt,
+                                  survive, irregular, lane_len, rid);
+            if (!(((survive | irregular) >> (lane >> lpr_log2)) & 1u)) dense_bytes += lane_len;
+            const uint32_t rid_lo = (uint32_t)rid;  // reads are indexed with 31 bits (query_device checks)
+            while (survive) {
+                const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
+                survive &= survive - 1u;
+                process_read(bcast_u32(rid_lo, (int)(jj << lpr_log2)), dlds.live[wave] + jj * rw);
+            }
+            while (irregular) {
+                const uint32_t jj = (uint32_t)__ffs((int)irregular) - 1u;
+                irregular &= irregular - 1u;
+                process_read(bcast_u32(rid_lo, (int)(jj << lpr_log2)), nullptr);
             }
         }
     } else if (LONG) {
