@@ -512,7 +512,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     t.last_n_reads = n_reads;
     PFQ_TRY(ensure_scratch(t, n_reads, want_hits));
     const size_t nl = t.leaves.size();
-    // bucketed path: threshold 1 (any certificate kernel), or 0 < threshold < 1 with probe records (per-k-mer miss bytes)
+    // bucketed path: threshold 1 (any certificate kernel), or 0 < threshold < 1 with probe records (per-pair k-mer miss bits)
     const bool thr_one = threshold == 1.0f, thr_frac = threshold > 0.0f && threshold < 1.0f;
     uint64_t rec_budget = 64ull << 30;
     if (const char *e = getenv("PFQ_RECORD_GB")) rec_budget = strtoull(e, nullptr, 10) << 30;

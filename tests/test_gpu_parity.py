@@ -298,19 +298,19 @@ def test_prune_tree_matches_oracle(gpu, depth):  # bloom_tree.rs:302-330
 # synthetic workload generators (bench data) and a BASELINE config-2-shaped case
 # ---------------------------------------------------------------------------------------------------------------
 def test_synthetic_generators_match_oracle(gpu):
-    import torch
+    from hipbuf import DeviceBuffer, synchronize
     from phagefilter_amd import _ffi
     n_g, glen, rlen, n_r = 5, 1000, 150, 4000
-    dg = torch.empty(n_g * glen, dtype=torch.uint8, device="cuda")
-    _ffi.check(_ffi.lib().pfq_synth_genomes_device(dg.data_ptr(), n_g, glen, 0x5EED0000, None))
+    dg = DeviceBuffer(n_g * glen)
+    _ffi.check(_ffi.lib().pfq_synth_genomes_device(dg.ptr, n_g, glen, 0x5EED0000, None))
     want_g = np.stack([np.frombuffer(orc.synth_genome(0x5EED0000 + i, glen), dtype=np.uint8) for i in range(n_g)])
-    torch.cuda.synchronize()
-    assert np.array_equal(dg.cpu().numpy().reshape(n_g, glen), want_g)
-    dr = torch.empty(n_r * rlen, dtype=torch.uint8, device="cuda")
-    _ffi.check(_ffi.lib().pfq_synth_reads_device(dr.data_ptr(), 100, n_r, rlen, dg.data_ptr(), glen, n_g, 0x5EED1234, None))
-    torch.cuda.synchronize()
+    synchronize()
+    assert np.array_equal(dg.to_numpy().reshape(n_g, glen), want_g)
+    dr = DeviceBuffer(n_r * rlen)
+    _ffi.check(_ffi.lib().pfq_synth_reads_device(dr.ptr, 100, n_r, rlen, dg.ptr, glen, n_g, 0x5EED1234, None))
+    synchronize()
     want_r = orc.synth_reads(0x5EED1234, 100, n_r, rlen, want_g, glen)
-    assert np.array_equal(dr.cpu().numpy().reshape(n_r, rlen), want_r)
+    assert np.array_equal(dr.to_numpy().reshape(n_r, rlen), want_r)
 
 
 def test_config2_shape_64_leaves_k21(gpu):
@@ -387,15 +387,14 @@ def _read_plan(seed, first, count, n_genomes):
 def test_config2_full_size_1m_reads_64_leaves(gpu):
     """BASELINE config 2 at its real size: 1 M synthetic 150 bp reads vs a 64-leaf SBT, k=21, nbits=71 887 936,
     10 hashes, 50 kbp genomes; per-leaf counts and every per-read hit set equal the oracle's, on both paths."""
-    import torch
-    from phagefilter_amd import _ffi
+    from hipbuf import DeviceBuffer
     n_g, glen, k, h, nbits, n_reads = 64, 50000, 21, 10, 71887936, 1000000
     seeds = (0x0123456789ABCDEF, 0xFEDCBA9876543210)
     genomes_np = np.stack([np.frombuffer(orc.synth_genome(0x5EED0000 + i, glen), dtype=np.uint8) for i in range(n_g)])
     ids = [f"G{i:05d}" for i in range(n_g)]
     ot = orc.build_balanced_tree([g.tobytes() for g in genomes_np], ids, k, nbits, h, *seeds)
-    dg = torch.from_numpy(genomes_np.reshape(-1).copy()).cuda()
-    gt = BloomTree.build_balanced_device(dg.data_ptr(), glen, n_g, ids, k, nbits, h, *seeds)
+    dg = DeviceBuffer.from_numpy(genomes_np.reshape(-1))
+    gt = BloomTree.build_balanced_device(dg.ptr, glen, n_g, ids, k, nbits, h, *seeds)
     for v in (0, 1, 63, 126):
         assert np.array_equal(gt.node_filter(v), ot.bits[v])
     reads_np = orc.synth_reads(0x5EED1234, 0, n_reads, 150, genomes_np, glen)
@@ -419,29 +418,29 @@ def test_config3_properties_1024_leaves(gpu):
     """BASELINE config 3/4 shape (1024-leaf SBT, full parameters) through size-independent properties: every
     positive read hits its source leaf; counts are additive over a partition of the reads (what read sharding across
     GPUs relies on) and independent of the query path and of the block size; false-positive leaves are rare."""
-    import torch
+    from hipbuf import DeviceBuffer, synchronize
     from phagefilter_amd import _ffi
     L = _ffi.lib()
     n_g, glen, k, h, nbits, n_reads = 1024, 50000, 21, 10, 71887936, 4 * 1024 * 1024
     ids = [f"G{i:05d}" for i in range(n_g)]
-    dg = torch.empty(n_g * glen, dtype=torch.uint8, device="cuda")
-    _ffi.check(L.pfq_synth_genomes_device(dg.data_ptr(), n_g, glen, 0x5EED0000, None))
-    torch.cuda.synchronize()
-    gt = BloomTree.build_balanced_device(dg.data_ptr(), glen, n_g, ids, k, nbits, h, 0x0123456789ABCDEF, 0xFEDCBA9876543210)
+    dg = DeviceBuffer(n_g * glen)
+    _ffi.check(L.pfq_synth_genomes_device(dg.ptr, n_g, glen, 0x5EED0000, None))
+    synchronize()
+    gt = BloomTree.build_balanced_device(dg.ptr, glen, n_g, ids, k, nbits, h, 0x0123456789ABCDEF, 0xFEDCBA9876543210)
     info = gt.info()
     assert (info.n_nodes, info.n_leaves, info.superset_verified) == (2047, 1024, 1)
-    dr = torch.empty(n_reads * 150 + 64, dtype=torch.uint8, device="cuda")
-    _ffi.check(L.pfq_synth_reads_device(dr.data_ptr(), 0, n_reads, 150, dg.data_ptr(), glen, n_g, 0x5EED1234, None))
-    off = torch.arange(n_reads + 1, dtype=torch.int64, device="cuda") * 150
-    torch.cuda.synchronize()
+    dr = DeviceBuffer(n_reads * 150 + 64)
+    _ffi.check(L.pfq_synth_reads_device(dr.ptr, 0, n_reads, 150, dg.ptr, glen, n_g, 0x5EED1234, None))
+    off = DeviceBuffer.from_numpy(np.arange(n_reads + 1, dtype=np.uint64) * 150)
+    synchronize()
     pos, leaf = _read_plan(0x5EED1234, 0, n_reads, n_g)
     expect = np.bincount(leaf[pos], minlength=n_g)
 
     def counts(path, lo, hi):
         gt.reset_counts()
         gt.set_path(path)
-        gt.query_device(dr.data_ptr() + lo * 150, off.data_ptr(), hi - lo, (hi - lo) * 150, 1.0, 0)
-        torch.cuda.synchronize()
+        gt.query_device(dr.ptr + lo * 150, off.ptr, hi - lo, (hi - lo) * 150, 1.0, 0)
+        synchronize()
         return np.array([c for _, c in gt.get_leaf_counts()], dtype=np.int64)
 
     whole = counts(1, 0, n_reads)
