@@ -102,6 +102,16 @@ def main() -> None:
         first = (b * world + rank) * B
         _ffi.check(L.pfq_synth_reads_device(reads.data_ptr() + b * B * rl, first, B, rl, src_genomes.data_ptr(), glen, n_g,
                                             READ_SEED, None))
+    err = float(os.environ.get("PFQ_BENCH_READ_ERRORS", "0"))
+    if err > 0:  # experiment: substitution errors in the reads (thresholds below 1 are made for these)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(777)
+        for b in range(n_batches):
+            view = reads[b * B * rl:(b + 1) * B * rl]
+            mut = torch.rand(view.numel(), device=dev, generator=gen) < err
+            alt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (view.numel(),), device=dev, generator=gen)]
+            view.copy_(torch.where(mut, alt, view))
+            del mut, alt
     off = torch.arange(B + 1, dtype=torch.int64, device=dev) * rl
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
