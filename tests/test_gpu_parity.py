@@ -614,3 +614,51 @@ def test_page_locked_host_buffers(gpu):
     _ffi.check(L.pfq_host_free(p_off))
     _ffi.check(L.pfq_host_free(None))
     gt.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# randomized configurations: every combination of tree width, read-length mix, threshold, query path and bucket
+# buffer size goes through the same comparison with the oracle (per-leaf counts and every per-read hit set)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_randomized_parity(gpu, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n_genomes = int(rng.choice([3, 17, 40, 130, 290, 520, 1040]))
+    k = int(rng.choice([9, 15, 20, 21, 31, 32, 47]))
+    h = int(rng.choice([2, 3, 7, 10, 17]))
+    nbits = int(rng.choice([40009, 131072, 300007, 1 << 20, 2500003]))
+    glen = int(rng.integers(max(k + 5, 60), 900))
+
+    def dna(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).astype(np.uint8))
+
+    base = [dna(glen) for _ in range(max(2, n_genomes // int(rng.choice([1, 3, 8]))))]
+    genomes = []
+    for i in range(n_genomes):
+        g = bytearray(base[int(rng.integers(0, len(base)))])
+        for _ in range(int(rng.integers(0, 6))):
+            g[int(rng.integers(0, len(g)))] = ord("ACGT"[int(rng.integers(0, 4))])
+        genomes.append(bytes(g))
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    reads = []
+    for _ in range(int(rng.integers(150, 500))):
+        src = genomes[int(rng.integers(0, n_genomes))] * int(rng.choice([1, 1, 1, 3, 25]))   # some reads span repeats: long reads
+        L = int(min(len(src), rng.choice([k, k + 1, 64 + k - 1, 100, 150, 151, 250, 300, 700, 2000, 20000])))
+        o = int(rng.integers(0, len(src) - L + 1))
+        r = bytearray(src[o:o + L])
+        for _ in range(int(rng.choice([0, 0, 1, 3, 10]))):
+            r[int(rng.integers(0, L))] = ord("ACGTN"[int(rng.integers(0, 5))])
+        reads.append(bytes(r) if rng.random() < 0.5 else orc.revcomp(bytes(r)))
+    reads += [dna(int(rng.integers(0, 400))) for _ in range(60)] + [b"", dna(k - 1)]
+    entries = int(rng.choice([0, 0, 30_000, 400_000, 5_000_000]))
+    if entries:
+        os.environ["PFQ_TILE_ENTRIES"] = str(entries)
+    try:
+        gt = gpu_tree(genomes, ids, k, nbits, h)
+        for thr in (1.0, float(rng.choice([0.05, 0.3, 0.5, 0.9])), float(rng.choice([0.0, 0.2, 0.75, 0.999, 1.5]))):
+            for path in (1, 0, 1):
+                check_query(gt, ot, reads, thr, path=path)
+        gt.close()
+    finally:
+        os.environ.pop("PFQ_TILE_ENTRIES", None)
