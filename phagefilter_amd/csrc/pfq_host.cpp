@@ -696,7 +696,8 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         ta.flag_list = t.d_flag_list.p;
                         ta.flag_cap = (uint32_t)std::min<uint64_t>(t.d_flag_list.n, 0xffffffffu);
                         ta.entry_cursor = t.d_cursors.p + 2;
-                        ta.entry_cap = forced_cap ? std::min<uint64_t>(forced_cap, t.d_entries.n) : t.d_entries.n;
+                        // (a multiple of 32 entries: buckets then start on 128-byte boundaries, k_tile_test reads them 16 bytes at a time)
+                        ta.entry_cap = (forced_cap ? std::min<uint64_t>(forced_cap, t.d_entries.n) : t.d_entries.n) & ~31ull;
                         ta.entries = t.d_entries.p;
                         ta.gfill = t.d_gfill.p;
                         ta.fail = t.d_fail.p;
