@@ -122,7 +122,10 @@ void pfq_tree_close(pfq_tree *tree);
 /* query::query_batch (query.rs:66-82) for one block of reads given as raw bytes: read i =
  * seq[offsets[i] .. offsets[i+1]) (HOST buffers).  k-mer extraction (file_parser.rs:135-148) happens on the
  * device.  Leaf counts accumulate across calls like BloomNode::mapped_reads (query.rs:143).  `hits` may be NULL
- * unless PFQ_WANT_HITS is set. */
+ * unless PFQ_WANT_HITS is set.  The input buffers may be reused as soon as the call returns.  Without
+ * PFQ_WANT_HITS the call returns when the block has been copied and its kernels are queued (the copy of the next
+ * block overlaps them); the calls that read results (pfq_leaf_counts, pfq_save_leaf_counts, pfq_last_stats,
+ * pfq_tree_close) wait for the device. */
 int pfq_query_batch(pfq_tree *tree, const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads, float threshold,
                     uint32_t flags, pfq_hits *hits);
 

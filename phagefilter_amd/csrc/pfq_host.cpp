@@ -117,7 +117,12 @@ struct pfq_tree {
     DevBuf<uint2> d_hit_pairs, d_pairs, d_sorted;
     DevBuf<uint32_t> d_bucket, d_fail;  // bucket: cnt[n], off[n+1], cur[n]
     DevBuf<unsigned int> d_queue;
-    DevBuf<uint8_t> d_allhit, d_seq;
+    DevBuf<uint8_t> d_allhit, d_seq, d_seq2;  // d_seq / d_seq2, d_off / d_off2: input buffers of pfq_query_batch, alternating
+    DevBuf<uint64_t> d_off2;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t in_free[2] = {nullptr, nullptr};
+    bool in_used[2] = {false, false};
+    int in_slot = 0;
     DevBuf<unsigned long long> d_miss_words;  // thresholds < 1: k-mer miss bits of every deferred pair
     DevBuf<uint32_t> d_miss_pos, d_bucket_w;  // first word per sorted pair; per-bucket word counts / offsets / cursors
     DevBuf<uint32_t> d_long;
@@ -1299,6 +1304,10 @@ void pfq_tree_close(pfq_tree *tree) {
     if (!tree) return;
     (void)hipSetDevice(tree->device);
     (void)hipDeviceSynchronize();
+    if (tree->copy_stream) {
+        (void)hipStreamDestroy(tree->copy_stream);
+        for (auto e : tree->in_free) (void)hipEventDestroy(e);
+    }
     if (tree->h_pair_cursor) (void)hipHostFree(tree->h_pair_cursor);
     if (tree->hint_ev) (void)hipEventDestroy(tree->hint_ev);
     delete tree;
@@ -1317,12 +1326,26 @@ int pfq_query_batch(pfq_tree *tree, const uint8_t *seq, const uint64_t *offsets,
     PFQ_TRY(use_device(tree->device));
     pfq_tree &t = *tree;
     uint64_t total = n_reads ? offsets[n_reads] : 0;
-    HIP_TRY(t.d_seq.ensure(total + 16));
-    HIP_TRY(t.d_off.ensure(n_reads + 1));
-    if (total) HIP_TRY(hipMemcpy(t.d_seq.p, seq, total, hipMemcpyHostToDevice));
-    if (n_reads) HIP_TRY(hipMemcpy(t.d_off.p, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice));
-    PFQ_TRY(query_device(t, t.d_seq.p, t.d_off.p, n_reads, total, threshold, flags, nullptr, hits));
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    // Two input buffers and a copy stream of its own: the copy of this block runs while the kernels of the previous
+    // block (which read the other buffer) are still at work.  A call that wants no hits returns once its kernels are
+    // queued; counts are read by calls that synchronise (pfq_leaf_counts, pfq_last_stats, pfq_tree_close).
+    if (!t.copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&t.copy_stream, hipStreamNonBlocking));
+        for (auto &e : t.in_free) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int slot = (t.in_slot ^= 1);
+    if (t.in_used[slot]) HIP_TRY(hipEventSynchronize(t.in_free[slot]));  // the kernels that read this buffer are done
+    DevBuf<uint8_t> &ds = slot ? t.d_seq2 : t.d_seq;
+    DevBuf<uint64_t> &dof = slot ? t.d_off2 : t.d_off;
+    HIP_TRY(ds.ensure(total + 16));
+    HIP_TRY(dof.ensure(n_reads + 1));
+    if (total) HIP_TRY(hipMemcpyAsync(ds.p, seq, total, hipMemcpyHostToDevice, t.copy_stream));
+    if (n_reads) HIP_TRY(hipMemcpyAsync(dof.p, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, t.copy_stream));
+    HIP_TRY(hipStreamSynchronize(t.copy_stream));
+    PFQ_TRY(query_device(t, ds.p, dof.p, n_reads, total, threshold, flags, nullptr, hits));
+    HIP_TRY(hipEventRecord(t.in_free[slot], nullptr));
+    t.in_used[slot] = true;
+    if (flags & PFQ_WANT_HITS) HIP_TRY(hipStreamSynchronize(nullptr));
     return PFQ_OK;
 }
 
