@@ -669,8 +669,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                     uint64_t want = (uint64_t)((double)total_bytes * t.num_hashes * 1.13 * std::max(1.0, t.pairs_per_read)) +
                                     max_chunks * n_tiles * 544ull;
                     if (want * 4 > tile_budget) want = tile_budget / 4;
-                    uint64_t forced_cap = 0;
-                    if (const char *e = getenv("PFQ_TILE_ENTRIES")) want = forced_cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // tests: force passes
+                    if (const char *e = getenv("PFQ_TILE_ENTRIES")) want = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // tests: force passes
                     hipError_t e1 = t.d_entries.ensure(want);
                     if (e1 != hipSuccess) {
                         (void)hipGetLastError();
@@ -702,7 +701,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         ta.flag_cap = (uint32_t)std::min<uint64_t>(t.d_flag_list.n, 0xffffffffu);
                         ta.entry_cursor = t.d_cursors.p + 2;
                         // (a multiple of 32 entries: buckets then start on 128-byte boundaries, k_tile_test reads them 16 bytes at a time)
-                        ta.entry_cap = (forced_cap ? std::min<uint64_t>(forced_cap, t.d_entries.n) : t.d_entries.n) & ~31ull;
+                        ta.entry_cap = std::min<uint64_t>(want, t.d_entries.n) & ~31ull;  // (the buffer only grows; the budget of this call is `want`)
                         ta.entries = t.d_entries.p;
                         ta.gfill = t.d_gfill.p;
                         ta.fail = t.d_fail.p;

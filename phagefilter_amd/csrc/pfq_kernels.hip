@@ -1220,11 +1220,11 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                     if (c == 0) continue;
                     const uint32_t pos = s_pos[t];
                     uint32_t *dst = a.entries + dsc.base + (uint64_t)t * dsc.cap;
-                    if (pos + c <= dsc.cap) {
-                        for (uint32_t i = lane; i < c; i += 64) dst[pos + i] = bins[t * BIN_STRIDE + i];
-                    } else {  // bucket full: the pairs whose probes are dropped take the fallback
-                        for (uint32_t i = lane; i < c; i += 64) flag_fallback(a, dsc.first + (bins[t * BIN_STRIDE + i] >> TILE_LOG2));
-                    }
+                    // what fits is written (k_tile_test reads min(fill, cap) entries: every slot below cap must hold a
+                    // real probe); the pairs whose probes are dropped — bucket full — take the fallback
+                    const uint32_t room = pos < dsc.cap ? dsc.cap - pos : 0u, wr = c < room ? c : room;
+                    for (uint32_t i = lane; i < wr; i += 64) dst[pos + i] = bins[t * BIN_STRIDE + i];
+                    for (uint32_t i = wr + lane; i < c; i += 64) flag_fallback(a, dsc.first + (bins[t * BIN_STRIDE + i] >> TILE_LOG2));
                 }
             };
             if (dsc.cap == 0) {  // no bucket space for this chunk
@@ -1255,10 +1255,13 @@ void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<8, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<16, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<16, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    const size_t lds_wide = (MAX_TILES + (size_t)a.n_tiles * 257) * 4;
-    if (lds_wide <= 148 * 1024 && !getenv("PFQ_BIN_NARROW")) {
+    const size_t lds_wide = (MAX_TILES + (size_t)a.n_tiles * 257) * 4, lds_wider = (MAX_TILES + (size_t)a.n_tiles * 513) * 4;
+    if (lds_wider <= 148 * 1024 && !getenv("PFQ_BIN_NARROW") && !getenv("PFQ_BIN_WIDE")) {
+        hipLaunchKernelGGL((k_tile_bin<16, 512>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_wider, st, a);
+    } else if (lds_wide <= 148 * 1024 && !getenv("PFQ_BIN_NARROW")) {
         hipLaunchKernelGGL((k_tile_bin<16, 256>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_wide, st, a);
     } else {
         const size_t lds = (MAX_TILES + (size_t)a.n_tiles * 129) * 4;
@@ -1267,7 +1270,7 @@ void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
 }
 
 constexpr uint32_t TEST_LOADS = 4;  // 16-byte entry loads in flight per thread (8 measured slower: 6.1 vs 5.9 ms)
-__global__ void __launch_bounds__(512) k_tile_test(TileArgs a) {
+__global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     extern __shared__ uint32_t s_tile[];  // 2^TILE_LOG2 bits
     const uint32_t tile_words = 1u << (TILE_LOG2 - 5);
     const uint64_t n_words32 = a.n_words * 2;
@@ -1337,7 +1340,7 @@ void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_tile_test, dim3(blocks), dim3(512), (size_t)(1u << (TILE_LOG2 - 3)), st, a);
+    hipLaunchKernelGGL(k_tile_test, dim3((blocks + 1) / 2), dim3(1024), (size_t)(1u << (TILE_LOG2 - 3)), st, a);
 }
 
 void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st) {
