@@ -132,7 +132,9 @@ int pfq_query_batch(pfq_tree *tree, const uint8_t *seq, const uint64_t *offsets,
 /* Same with the block already resident in HBM (device pointers) on HIP stream `stream` (hipStream_t, may be
  * NULL for the default stream).  total_bytes = offsets[n_reads], the size of the sequence buffer (0 if unknown:
  * the library then skips optimisations that need it).  Asynchronous unless PFQ_WANT_HITS is set; counts are final
- * after the stream is synchronised.  This is the entry the benchmark times. */
+ * after the stream is synchronised.  The tree's scratch buffers are reused call after call: calls on one stream are
+ * ordered by it; a call on another stream than the previous one (pfq_query_batch uses the default stream) first waits
+ * for that one.  This is the entry the benchmark times. */
 int pfq_query_batch_device(pfq_tree *tree, const uint8_t *d_seq, const uint64_t *d_offsets, uint64_t n_reads,
                            uint64_t total_bytes, float threshold, uint32_t flags, void *stream, pfq_hits *hits);
 

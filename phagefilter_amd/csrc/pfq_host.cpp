@@ -131,6 +131,7 @@ struct pfq_tree {
     DevBuf<uint64_t> d_off;
     DevBuf<unsigned long long> d_counts_snapshot;
     hipStream_t last_stream = nullptr;
+    bool have_last_stream = false;
     int force_path = -1;
     // ---- profiling (HIP events on the launch stream)
     std::vector<hipEvent_t> prof_ev;  // PROF_EV events per recorded call
@@ -515,7 +516,10 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     const bool want_hits = (flags & PFQ_WANT_HITS) != 0;
     if (want_hits && !hits) return fail(PFQ_ERR_ARG, "PFQ_WANT_HITS set but hits == NULL");
     if (n_reads >= (1ull << 31) - 1024) return fail(PFQ_ERR_ARG, "more than 2^31 reads in one block");
+    // the scratch buffers are reused call after call: calls on one stream are ordered by it, a change of stream waits
+    if (t.have_last_stream && t.last_stream != st) HIP_TRY(hipStreamSynchronize(t.last_stream));
     t.last_stream = st;
+    t.have_last_stream = true;
     t.last_n_reads = n_reads;
     PFQ_TRY(ensure_scratch(t, n_reads, want_hits));
     const size_t nl = t.leaves.size();
