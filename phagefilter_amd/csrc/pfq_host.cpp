@@ -720,7 +720,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         // spreads the chunks over passes that reuse it.  Their number is known on the device only; as
                         // many passes as the previous call needed are launched without waiting, and chunks of later
                         // passes (if any) are certified by the record kernel below — exact either way.
-                        const uint64_t n_passes = std::max<uint64_t>(1, t.passes_hint);
+                        const uint64_t n_passes = std::min<uint64_t>(std::max<uint64_t>(1, t.passes_hint), 256);  // (more: the record kernel takes the rest)
                         for (uint64_t p = 0; p < n_passes; ++p) {
                             ta.pass = (uint32_t)p;
                             pfq::launch_tile_bin(ta, bin_blocks, st);

@@ -1035,13 +1035,20 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
             uint32_t cap = (uint32_t)((mean + (mean >> 3) + 512 + 31) & ~31ull);
             unsigned long long need = (unsigned long long)cap * a.n_tiles;
             // The bucket space is virtual: position / entry_cap is the pass in which the chunk is binned and tested,
-            // position % entry_cap its place in the (reused) buffer.  A reservation that would straddle two passes is
-            // dropped and taken again (the cursor has moved past the boundary by then).
+            // position % entry_cap its place in the (reused) buffer.  A reservation never straddles two passes: the
+            // cursor is moved with a compare-and-swap, to the next pass boundary first when the chunk does not fit the
+            // rest of the current pass (an add-and-retry scheme would burn a whole `need` per failed attempt and
+            // inflate the number of passes without bound when need is close to the capacity).
             unsigned long long base = 0;
-            bool fits = need <= a.entry_cap;
-            while (fits) {
-                base = atomicAdd(a.entry_cursor, need);
-                if (base % a.entry_cap + need <= a.entry_cap) break;
+            const bool fits = need <= a.entry_cap;
+            if (fits) {
+                unsigned long long seen = atomicAdd(a.entry_cursor, 0ull);
+                while (true) {
+                    base = (seen % a.entry_cap + need <= a.entry_cap) ? seen : (seen / a.entry_cap + 1ull) * a.entry_cap;
+                    const unsigned long long prev = atomicCAS(a.entry_cursor, seen, base + need);
+                    if (prev == seen) break;
+                    seen = prev;
+                }
             }
             ChunkDesc dsc;
             dsc.row = a.meta[first].w;
