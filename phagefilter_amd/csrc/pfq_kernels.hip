@@ -1034,37 +1034,61 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
             unsigned long long mean = (s_sum * a.hp.num_hashes + a.n_tiles - 1) / a.n_tiles;
             uint32_t cap = (uint32_t)((mean + (mean >> 3) + 512 + 31) & ~31ull);
             unsigned long long need = (unsigned long long)cap * a.n_tiles;
-            // The bucket space is virtual: position / entry_cap is the pass in which the chunk is binned and tested,
-            // position % entry_cap its place in the (reused) buffer.  A reservation never straddles two passes: the
-            // cursor is moved with a compare-and-swap, to the next pass boundary first when the chunk does not fit the
-            // rest of the current pass (an add-and-retry scheme would burn a whole `need` per failed attempt and
-            // inflate the number of passes without bound when need is close to the capacity).
-            unsigned long long base = 0;
+            // (where the chunk's buckets go — pass and position in the reused buffer — is decided by k_tile_assign)
             const bool fits = need <= a.entry_cap;
-            if (fits) {
-                unsigned long long seen = atomicAdd(a.entry_cursor, 0ull);
-                while (true) {
-                    base = (seen % a.entry_cap + need <= a.entry_cap) ? seen : (seen / a.entry_cap + 1ull) * a.entry_cap;
-                    const unsigned long long prev = atomicCAS(a.entry_cursor, seen, base + need);
-                    if (prev == seen) break;
-                    seen = prev;
-                }
-            }
             ChunkDesc dsc;
             dsc.row = a.meta[first].w;
             dsc.first = first;
             dsc.n = n;
             dsc.cap = fits ? cap : 0u;   // a single chunk larger than the whole buffer: its pairs take the fallback
-            dsc.base = fits ? base % a.entry_cap : 0ull;
+            dsc.base = 0;
             dsc.leaf = c;
-            dsc.pass = fits ? (uint32_t)(base / a.entry_cap) : 0u;
+            dsc.pass = 0;
             a.chunks[chunk] = dsc;
         }
         __syncthreads();
     }
 }
+// The bucket space is virtual: pass = position / entry_cap, place in the (reused) buffer = position % entry_cap.
+// One wave packs the chunks in order, 64 at a time: a chunk that does not fit the rest of the current pass starts the
+// next one, so no reservation straddles two passes.  (Reserving with atomics from the plan blocks was tried twice:
+// add-and-retry inflates the pass count without bound when a chunk nearly fills the buffer; compare-and-swap on one
+// word from 1024 blocks cost 5 ms.)  entry_cursor receives the end of the packing, for the host's pass count.
+__global__ void __launch_bounds__(64) k_tile_assign(TileArgs a) {
+    const uint32_t lane = lane_id();
+    const uint32_t n_chunks = *a.n_chunks < a.max_chunks ? *a.n_chunks : a.max_chunks;
+    unsigned long long off = 0;  // wave-uniform
+    uint32_t pass = 0;
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const uint32_t cap = c < n_chunks ? a.chunks[c].cap : 0u;
+        const unsigned long long need = (unsigned long long)cap * a.n_tiles;
+        unsigned long long my_off = 0;
+        uint32_t my_pass = 0;
+        for (int i = 0; i < 64; ++i) {
+            const unsigned long long ni = ((unsigned long long)bcast_u32((uint32_t)(need >> 32), i) << 32) | bcast_u32((uint32_t)need, i);
+            if (ni == 0) continue;
+            if (off + ni > a.entry_cap) {
+                ++pass;
+                off = 0;
+            }
+            if ((int)lane == i) {
+                my_off = off;
+                my_pass = pass;
+            }
+            off += ni;
+        }
+        if (cap) {
+            a.chunks[c].base = my_off;
+            a.chunks[c].pass = my_pass;
+        }
+    }
+    if (lane == 0) *a.entry_cursor = (unsigned long long)pass * a.entry_cap + off;
+}
 void launch_tile_plan(const TileArgs &a, hipStream_t st) {
-    if (a.n_leaves) hipLaunchKernelGGL(k_tile_plan, dim3(a.n_leaves), dim3(256), 0, st, a);
+    if (!a.n_leaves) return;
+    hipLaunchKernelGGL(k_tile_plan, dim3(a.n_leaves), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_tile_assign, dim3(1), dim3(64), 0, st, a);
 }
 
 // BIN_WAVES pairs are binned per round by one block, BIN_CAP LDS entries per tile and round (mean ~75 per 8 pairs at
