@@ -6,6 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <thread>
+#include <mutex>
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -1027,37 +1030,97 @@ static int open_impl(const char *db_dir, int device, bool shard, uint64_t shard_
             t->filter_paths.push_back(nd.bf_path);
         } else nd.filter = it->second;
     }
-    bool first = true;
-    std::vector<uint8_t> fb;
-    for (size_t f = 0; f < t->filter_paths.size(); ++f) {
-        const std::string path = dir + "/" + t->filter_paths[f];
-        if (!read_file(path, fb))
-            return fail(PFQ_ERR_IO, "cannot read Bloom filter file " + path + " (reference: panic at bloom_filter.rs:155)");
+    // One .bf per filter: read, check, upload.  The first one fixes the geometry; the others are loaded by a few
+    // threads side by side (a 1024-leaf database is 2047 files of 9 MB: reading them one after the other takes longer
+    // than classifying a hundred million reads).  Returns a status and leaves the message in `msg`.
+    pfq_tree *tp = t.get();
+    auto load_one = [&](size_t f, std::vector<uint8_t> &fb, bool first, std::string &msg) -> int {
+        const std::string path = dir + "/" + tp->filter_paths[f];
+        if (!read_file(path, fb)) {
+            msg = "cannot read Bloom filter file " + path + " (reference: panic at bloom_filter.rs:155)";
+            return PFQ_ERR_IO;
+        }
         Cur b{fb.data(), fb.size()};
         std::string order = b.str();
         uint8_t width = b.u8(), index = b.u8();
         uint64_t nbits = b.u64(), nwords = b.u64();
-        if (!b.ok || order != ORDER_NAME || width != 64 || index != 0 || nwords != (nbits + 63) / 64)
-            return fail(PFQ_ERR_FORMAT, path + ": not a BitVec<usize, Lsb0> BloomFilter (order/head/length mismatch)");
+        if (!b.ok || order != ORDER_NAME || width != 64 || index != 0 || nwords != (nbits + 63) / 64) {
+            msg = path + ": not a BitVec<usize, Lsb0> BloomFilter (order/head/length mismatch)";
+            return PFQ_ERR_FORMAT;
+        }
         const uint8_t *words = b.take((size_t)nwords * 8);
         uint32_t nh = b.u32();
         uint64_t s1 = b.u64(), s2 = b.u64();
         uint8_t ptag = b.u8();
         if (b.ok && ptag == 1) (void)b.str();
-        if (!b.ok || ptag > 1 || b.p != b.n) return fail(PFQ_ERR_FORMAT, path + ": truncated or trailing bytes");
-        if (first) {
-            t->nbits = nbits;
-            t->num_hashes = nh;
-            PFQ_TRY(setup_hash_params(*t));
-            HIP_TRY(t->d_bits.ensure(t->filter_paths.size() * t->n_words));
-            t->n_rows = t->row_capacity = t->filter_paths.size();
-            first = false;
+        if (!b.ok || ptag > 1 || b.p != b.n) {
+            msg = path + ": truncated or trailing bytes";
+            return PFQ_ERR_FORMAT;
         }
-        if (nbits != t->nbits || nh != t->num_hashes)
-            return fail(PFQ_ERR_UNSUPPORTED, path + ": filter size / num_hashes differ from the other nodes");
-        if (s1 != t->seed1 || s2 != t->seed2)
-            return fail(PFQ_ERR_UNSUPPORTED, path + ": hash seeds differ from tree.bin's (node-independent indices need one seed pair)");
-        HIP_TRY(hipMemcpy(t->d_bits.p + f * t->n_words, words, (size_t)nwords * 8, hipMemcpyHostToDevice));
+        if (first) {
+            tp->nbits = nbits;
+            tp->num_hashes = nh;
+            int rc = setup_hash_params(*tp);
+            if (rc != PFQ_OK) {
+                msg = g_err;
+                return rc;
+            }
+            if (tp->d_bits.ensure(tp->filter_paths.size() * tp->n_words) != hipSuccess) {
+                (void)hipGetLastError();
+                msg = "not enough device memory for " + std::to_string(tp->filter_paths.size()) + " filters";
+                return PFQ_ERR_DEVICE;
+            }
+            tp->n_rows = tp->row_capacity = tp->filter_paths.size();
+        }
+        if (nbits != tp->nbits || nh != tp->num_hashes) {
+            msg = path + ": filter size / num_hashes differ from the other nodes";
+            return PFQ_ERR_UNSUPPORTED;
+        }
+        if (s1 != tp->seed1 || s2 != tp->seed2) {
+            msg = path + ": hash seeds differ from tree.bin's (node-independent indices need one seed pair)";
+            return PFQ_ERR_UNSUPPORTED;
+        }
+        if (hipMemcpy(tp->d_bits.p + f * tp->n_words, words, (size_t)nwords * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            msg = std::string("hipMemcpy of ") + path + ": " + hipGetErrorString(hipGetLastError());
+            return PFQ_ERR_DEVICE;
+        }
+        return PFQ_OK;
+    };
+    const size_t n_files = t->filter_paths.size();
+    if (n_files) {
+        std::vector<uint8_t> fb;
+        std::string msg;
+        int rc = load_one(0, fb, true, msg);
+        if (rc != PFQ_OK) return fail(rc, msg);
+    }
+    if (n_files > 1) {
+        unsigned n_threads = (unsigned)std::min<size_t>(8, n_files - 1);
+        if (const char *e = getenv("PFQ_LOAD_THREADS")) n_threads = (unsigned)std::min<size_t>(std::max(1, atoi(e)), n_files - 1);
+        std::atomic<size_t> next{1};
+        std::mutex err_mu;
+        int err_rc = PFQ_OK;
+        size_t err_file = ~(size_t)0;  // the lowest-numbered failing file is reported, like a sequential reader would
+        std::string err_msg;
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < n_threads; ++w)
+            pool.emplace_back([&] {
+                (void)hipSetDevice(device);
+                std::vector<uint8_t> fb;
+                std::string msg;
+                for (size_t f; (f = next.fetch_add(1)) < n_files;) {
+                    int rc = load_one(f, fb, false, msg);
+                    if (rc != PFQ_OK) {
+                        std::lock_guard<std::mutex> lk(err_mu);
+                        if (f < err_file) {
+                            err_file = f;
+                            err_rc = rc;
+                            err_msg = msg;
+                        }
+                    }
+                }
+            });
+        for (auto &th : pool) th.join();
+        if (err_rc != PFQ_OK) return fail(err_rc, err_msg);
     }
     if (t->root >= 0) PFQ_TRY(verify_supersets(*t));
     *out = t.release();
