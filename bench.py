@@ -180,7 +180,8 @@ def main() -> None:
         if os.path.exists(tpath):  # HBM bytes per launch from a separate rocprofv3 --pmc pass of this same workload
             try:
                 tj = json.load(open(tpath))
-                if tj.get("reads_per_step") == B and tj.get("leaves") == n_g:
+                if (tj.get("reads_per_step") == B and tj.get("leaves") == n_g and args.threshold == 1.0 and rl == 150
+                        and not any(os.environ.get(v) for v in ("PFQ_BENCH_FAMILY", "PFQ_BENCH_READ_ERRORS", "PFQ_BENCH_ALL_NEGATIVE"))):
                     per_kernel_traffic = tj.get("hbm_bytes_per_launch", {})
             except Exception:
                 per_kernel_traffic = {}
@@ -199,6 +200,9 @@ def main() -> None:
             {"kernel": "k_verify", "ms": prof.verify_ms / calls, "algorithmic_bytes": cert_bytes if (st.path == 1 and not st.tile_mode) else 0,
              "hbm_bytes": per_kernel_traffic.get("k_verify_rec")},
         ]
+        kernels_ms = sum(kern.values()) / calls
+        whole_gbs = int(st.algorithmic_bytes) / (kernels_ms * 1e-3) / 1e9 if kernels_ms > 0 else 0.0
+        whole_traffic = sum(v for v in per_kernel_traffic.values() if v) if per_kernel_traffic else None
         result = {
             "metric": "reads/sec classified (150 bp, 1024-leaf SBT) at 1/2/4/8 MI355X; bit-exact vs CPU",
             "value": total_reads / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,13 +213,17 @@ def main() -> None:
                        "reads_per_step_per_gpu": B, "read_len": rl, "leaves": n_g, "k": K, "nbits": NBITS,
                        "num_hashes": NUM_HASHES, "threshold": args.threshold,
                        "parallelism": f"reads sharded x{world}, tree replicated per GPU, one RCCL all-reduce of per-genome counts"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom, "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": alg,
-                         # SURVEY §8d's whole-path form: sum of A(r) over the reads of a step / time of a step (per GPU)
-                         "whole_path": {"achieved": int(st.algorithmic_bytes) / (elapsed / args.steps) / 1e9, "unit": "GB/s",
-                                        "frac": int(st.algorithmic_bytes) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
-                                        "algorithmic_bytes_per_step": int(st.algorithmic_bytes)}},
+            # SURVEY §8d's contract figure: A(r) summed over the reads of one step (one launch sequence) / the time of the
+            # kernels of that step (HIP events on the launch stream).  The path is a sequence of kernels none of which
+            # dominates, so the object describes the sequence; `certificate_stage` is the stage that produces the
+            # certificates (the algorithmic bytes beyond the reads themselves) on its own.
+            "roofline": {"bound": "hbm", "achieved": whole_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": whole_gbs / HBM_PEAK_GBS, "traffic": whole_traffic,
+                         "kernel": "whole step: " + " + ".join(k for k, v in kern.items() if v > 0),
+                         "avg_launch_ms": kernels_ms, "algorithmic_bytes_per_launch": int(st.algorithmic_bytes),
+                         "certificate_stage": {"kernel": dom, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                                               "traffic": traffic, "avg_launch_ms": avg_ms,
+                                               "algorithmic_bytes_per_launch": alg}},
             "query_path": "bucketed(screen+L2-sliced verify)" if st.path == 1 else "direct",
             "n_slices": int(st.n_slices), "tile_mode": int(st.tile_mode), "fallback_pairs": int(st.n_fallback_pairs),
             "tile_chunks": int(st.n_chunks), "tile_entries": int(st.tile_entries),
