@@ -338,6 +338,25 @@ def test_config2_shape_64_leaves_k21(gpu):
         assert gt.last_stats().path == path
     # every positive read hits (at least) its source leaf: about half of the reads
     assert 0.49 * n_reads < len(ohits) < 0.52 * n_reads
+    # thresholds below 1 at the same size (>= 2^18 reads: the bucketed path is chosen on its own), reads with errors
+    rng = np.random.default_rng(99)
+    noisy = seq.copy()
+    where = rng.random(noisy.size - 16) < 0.02
+    noisy[:-16][where] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(where.sum()))
+    for thr in (0.3, 0.7):
+        for v in range(ot.n_nodes):
+            ot.mapped_reads[v] = 0
+        oh, _, _ = orc.query_batch_packed(ot, noisy, off, thr, threads=8)
+        gt.reset_counts()
+        gt.set_path(-1)
+        offs, leaves = gt.query_packed(noisy, off, thr, want_hits=True)
+        assert gt.last_stats().path == 1
+        assert gt.get_leaf_counts() == ot.leaf_counts(), thr
+        got = np.stack([np.repeat(np.arange(n_reads), np.diff(offs).astype(np.int64)), leaves.astype(np.int64)], 1)
+        assert np.array_equal(got, np.array(oracle_hits(ot, oh), dtype=np.int64).reshape(-1, 2)), thr
+    for v in range(ot.n_nodes):
+        ot.mapped_reads[v] = 0
+    orc.query_batch_packed(ot, seq, off, 1.0, threads=8)     # (restore the threshold-1 counts used below)
     gt.close()
     # The probe buckets are reused pass after pass when they cannot hold all pairs.  The first call does not know how
     # many passes the plan needs (one is launched, the record kernel certifies the chunks of the others); the next
