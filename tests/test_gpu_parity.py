@@ -433,7 +433,8 @@ def test_config2_full_size_1m_reads_64_leaves(gpu):
     gt.close()
 
 
-def test_config3_properties_1024_leaves(gpu):
+@pytest.mark.parametrize("thr", [1.0, 0.3])
+def test_config3_properties_1024_leaves(gpu, thr):
     """BASELINE config 3/4 shape (1024-leaf SBT, full parameters) through size-independent properties: every
     positive read hits its source leaf; counts are additive over a partition of the reads (what read sharding across
     GPUs relies on) and independent of the query path and of the block size; false-positive leaves are rare."""
@@ -458,7 +459,7 @@ def test_config3_properties_1024_leaves(gpu):
     def counts(path, lo, hi):
         gt.reset_counts()
         gt.set_path(path)
-        gt.query_device(dr.ptr + lo * 150, off.ptr, hi - lo, (hi - lo) * 150, 1.0, 0)
+        gt.query_device(dr.ptr + lo * 150, off.ptr, hi - lo, (hi - lo) * 150, thr, 0)
         synchronize()
         return np.array([c for _, c in gt.get_leaf_counts()], dtype=np.int64)
 
