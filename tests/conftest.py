@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the native pieces are built in-tree (git-ignored): build them when a checkout arrives without them
+    import subprocess
+    need = [os.path.join(ROOT, "phagefilter_amd", "libpfq.so"), os.path.join(ROOT, "phagefilter_amd", "phage_filter"),
+            os.path.join(ROOT, "oracle", "libpfq_oracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "phagefilter_amd", "csrc")])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 
 def _has_gpu() -> bool:
