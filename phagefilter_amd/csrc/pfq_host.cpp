@@ -95,6 +95,9 @@ struct pfq_tree {
     hipEvent_t hint_ev = nullptr;
     uint64_t hint_reads = 0, hint_entry_cap = 0, passes_hint = 1;
     double pairs_per_read = 1.0, hits_per_read = 1.0;
+    double dirty_frac = 1.0;           // thresholds < 1: share of the last call's deferred pairs with a k-mer missing (1: unknown)
+    bool hint_counts = false;
+    uint32_t last_sub_log2 = 0;
     bool topology_dirty = false;       // nodes appended by pfq_tree_insert: renumber + verify before the next use
     uint64_t internal_counter = 0;     // names of internal nodes created by pfq_tree_insert
     size_t n_rows = 0, row_capacity = 0;  // filter rows in use / allocated in d_bits
@@ -112,7 +115,7 @@ struct pfq_tree {
     DevBuf<uint32_t> d_S, d_col_row, d_guard_off, d_guard_col;
     DevBuf<unsigned long long> d_counts;
     // ---- query scratch
-    DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit, [1] pair, [2] tile entries, [3] lo: chunks, hi: flagged pairs, [4] long reads
+    DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit, [1] pair, [2] tile entries, [3] lo: chunks, hi: flagged pairs, [4] long reads, [5] miss words, [6] dirty pairs, [7] open pairs after the tile passes
     DevBuf<uint32_t> d_entries, d_pair_chunk, d_leaf_chunk0, d_flag_list;  // LDS-tile certificates
     DevBuf<pfq::ChunkDesc> d_chunks;
     DevBuf<unsigned int> d_gfill;
@@ -488,11 +491,12 @@ constexpr uint64_t CLASSIFY_MAX_BLOCKS = 4096;  // blocks of 4 waves; every wave
 int ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads) {
     if (!t.h_pair_cursor) {
         HIP_TRY(hipHostMalloc((void **)&t.h_pair_cursor, 64, hipHostMallocDefault));
-        t.h_pair_cursor[0] = t.h_pair_cursor[1] = 0;
+        for (int i = 0; i < 8; ++i) t.h_pair_cursor[i] = 0;
         HIP_TRY(hipEventCreateWithFlags(&t.hint_ev, hipEventDisableTiming));
     } else if (t.hint_reads && hipEventQuery(t.hint_ev) == hipSuccess) {
         t.pairs_per_read = std::max(t.pairs_per_read, (double)t.h_pair_cursor[0] / (double)t.hint_reads);
         if (t.hint_entry_cap) t.passes_hint = std::max<uint64_t>(1, (t.h_pair_cursor[1] + t.hint_entry_cap - 1) / t.hint_entry_cap);
+        if (t.hint_counts) t.dirty_frac = (double)t.h_pair_cursor[2] / (double)std::max<unsigned long long>(1, t.h_pair_cursor[3] & 0xffffffffull);
         t.hint_reads = 0;
     }
     (void)hipGetLastError();  // hipEventQuery reports "not ready" through the error state
@@ -586,6 +590,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 uint32_t sub_log2 = 0;
                 while (sub_log2 < 6 && (nl << sub_log2) < 1024) ++sub_log2;
                 const size_t nb = nl << sub_log2;
+                t.last_sub_log2 = sub_log2;
                 uint32_t *cnt = t.d_bucket.p, *off = cnt + nb, *cur = off + nb + 1;
                 a.pairs = t.d_pairs.p;
                 a.pair_cap = t.d_pairs.n & ~31ull;  // whole reservations only (PAIR_CHUNK = 32)
@@ -667,7 +672,13 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 // LDS-tile certificates: every probe binned by (leaf chunk, 128 KiB filter tile), tiles tested out of LDS;
                 // k_verify_rec then only sees the pairs that could not be binned
                 const uint32_t n_tiles = (uint32_t)((t.n_words * 64 + (1ull << pfq::TILE_LOG2) - 1) >> pfq::TILE_LOG2);
-                bool tile_mode = recs && !counts_mode && n_tiles < pfq::MAX_TILES;
+                // Thresholds < 1: a tile pass tells the pairs with every k-mer contained (nothing to count) from the rest, which
+                // k_verify_rec then takes for their exact miss bits.  That pays when few pairs miss a k-mer (config 3, theta 0.3:
+                // 50 ms per step instead of 61 with none, 58 with 14 %, 65 with 36 %: break-even near a quarter); the share is the
+                // last call's (unknown: record kernel only).  Results do not depend on the choice.
+                bool tile_counts = t.dirty_frac < 0.2;
+                if (const char *e = getenv("PFQ_TILE_COUNTS")) tile_counts = atoi(e) != 0;
+                bool tile_mode = recs && (!counts_mode || tile_counts) && n_tiles < pfq::MAX_TILES;
                 if (const char *e = getenv("PFQ_TILE")) tile_mode = tile_mode && atoi(e) != 0;
                 uint64_t tile_budget = 64ull << 30;
                 if (const char *e = getenv("PFQ_TILE_GB")) tile_budget = strtoull(e, nullptr, 10) << 30;
@@ -752,6 +763,14 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 pfq::launch_verify(v, vblocks, vthreads, st);
                 if (v.only_flagged == 1) {  // many flagged pairs (no room for their probe buckets): walk all pairs in leaf order instead
                     v.only_flagged = 2;
+                    if (counts_mode) {
+                        // thresholds < 1: the walk is the only launch that works (pairs with a k-mer missing are on no list);
+                        // larger queue items (the walk pulls an item per 64 pairs, not per 8), and none at all when the tile
+                        // passes left no pair open
+                        pfq::launch_count_open(t.d_fail.p, off + nb, t.d_cursors.p + 7, st);
+                        v.n_open = t.d_cursors.p + 7;
+                        v.chunk = 8;
+                    }
                     pfq::launch_verify(v, vblocks, vthreads, st);
                 }
                 if (ev) HIP_TRY(hipEventRecord(ev[5], st));
@@ -771,6 +790,8 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 f.hit_cap = hit_cap;
                 f.hit_cursor = t.d_cursors.p;
                 f.stats = t.d_stats.p;
+                f.n_dirty = t.d_cursors.p + 6;
+                t.hint_counts = counts_mode;
                 pfq::launch_finalize(f, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[6], st));
             } else {
@@ -781,6 +802,9 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
         }
         if (bucketed) {  // how many pair slots this call used, for the next call's sizing
             HIP_TRY(hipMemcpyAsync(t.h_pair_cursor, t.d_cursors.p + 1, 16, hipMemcpyDeviceToHost, st));  // pair cursor, bucket cursor
+            HIP_TRY(hipMemcpyAsync(t.h_pair_cursor + 2, t.d_cursors.p + 6, 8, hipMemcpyDeviceToHost, st));  // pairs with a k-mer missing
+            if (n_reads && nl)  // ... of how many sorted pairs (the pair cursor also counts partly used reservations)
+                HIP_TRY(hipMemcpyAsync(t.h_pair_cursor + 3, t.d_bucket.p + 2 * (nl << t.last_sub_log2), 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipEventRecord(t.hint_ev, st));
             t.hint_reads = n_reads;
         }

@@ -862,8 +862,10 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
         const unsigned int nf = *a.n_flagged;
         leftover = a.entry_cursor && *a.entry_cursor > (unsigned long long)a.launched_passes * a.entry_cap;
         const bool many = (uint64_t)nf * 16u > (uint64_t)*a.n_pairs_ptr || nf > a.flag_cap;
-        const bool scan = many || leftover;
+        // thresholds < 1 after the tile passes: the pairs with a k-mer missing (bit 0) are not on the list, so scan
+        const bool scan = many || leftover || a.miss_words != nullptr;
         if (a.only_flagged == 1 ? (nf == 0 || scan) : !scan) return;
+        if (a.miss_words && a.n_open && *a.n_open == 0 && !leftover) return;  // every pair certified clean by the tile passes
     }
     const bool from_list = a.only_flagged == 1, skip_certified = a.only_flagged == 2;
     const uint64_t n_pairs = from_list ? *a.n_flagged : *a.n_pairs_ptr;
@@ -880,7 +882,9 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
         const uint64_t i = it * item_pairs + (uint64_t)wave * per_wave + lane;
         bool ok = it < n_items && lane < per_wave && i < n_pairs;
         e_idx = ok ? pair_index(i) : 0u;
-        if (ok && skip_certified && !(a.fail[e_idx] & 2u)) {  // certified by a tile pass ... if its pass was launched
+        // certified by a tile pass ... if its pass was launched.  Thresholds < 1: a tile pass only certifies pairs with no
+        // k-mer missing (fail == 0, miss words stay zero); a pair with bit 0 set still needs its missing k-mers counted here
+        if (ok && skip_certified && !(a.fail[e_idx] & (a.miss_words ? 3u : 2u))) {
             bool pending = false;
             if (leftover) {
                 const uint32_t c = a.pair_chunk[e_idx];
@@ -1374,6 +1378,16 @@ void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_tile_test, dim3((blocks + 1) / 2), dim3(1024), (size_t)(1u << (TILE_LOG2 - 3)), st, a);
 }
 
+__global__ void __launch_bounds__(256) k_count_open(const uint32_t *fail, const uint32_t *n_pairs_ptr, unsigned long long *out) {
+    const uint32_t n = *n_pairs_ptr;
+    uint32_t c = 0;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) c += fail[e] != 0u;
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if (lane_id() == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+void launch_count_open(const uint32_t *fail, const uint32_t *n_pairs_ptr, unsigned long long *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_count_open, dim3(512), dim3(256), 0, st, fail, n_pairs_ptr, out);
+}
 void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st) {
     if (a.recs) hipLaunchKernelGGL(k_verify_rec, dim3(blocks), dim3(threads), 0, st, a);
     else hipLaunchKernelGGL(k_verify, dim3(blocks), dim3(256), 0, st, a);
@@ -1386,6 +1400,7 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
         if (threadIdx.x == 0) { s_cnt = 0; s_bytes = 0; }
         __syncthreads();
         unsigned long long cnt = 0, bytes = 0;
+        uint32_t dirty = 0;
         for (uint32_t e = a.bucket_off[c << a.sub_log2] + threadIdx.x; e < a.bucket_off[(c + 1) << a.sub_log2]; e += blockDim.x) {
             uint2 p = a.sorted[e];
             const uint64_t o0 = a.off[p.x], L = a.off[p.x + 1] - o0, n = L - a.hp.k + 1;
@@ -1399,6 +1414,7 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
                 for (uint32_t w = 0; w < nw; ++w) missing += (uint64_t)__popcll(mw[w]);
                 need = need_kmers(a.threshold, n);
                 pass = n - missing >= need;
+                dirty += missing != 0;
             } else pass = !(a.fail[e] & 1u);
             if (pass) {
                 ++cnt;
@@ -1412,8 +1428,10 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
         for (int d = 32; d > 0; d >>= 1) {
             cnt += __shfl_down(cnt, d);
             bytes += __shfl_down(bytes, d);
+            dirty += __shfl_down(dirty, d);
         }
         if (lane_id() == 0 && cnt) { atomicAdd(&s_cnt, cnt); atomicAdd(&s_bytes, bytes); }
+        if (lane_id() == 0 && dirty && a.n_dirty) atomicAdd(a.n_dirty, (unsigned long long)dirty);
         __syncthreads();
         if (threadIdx.x == 0 && s_cnt) {
             atomicAdd(&a.counts[c], s_cnt);

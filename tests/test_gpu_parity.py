@@ -171,7 +171,7 @@ def test_query_matches_oracle(gpu, n_genomes, k, nbits, h):
         assert st.path == 0
     for thr in (0.3, 0.5, 0.75, 0.999):                            # bucketed at thresholds < 1: per-k-mer miss bytes
         st = check_query(gt, ot, reads, thr, path=1)
-        assert st.path == 1 and st.tile_mode == 0
+        assert st.path == 1    # (tile passes or not: chosen from the previous call's share of clean pairs)
     for thr in (0.0, 1.5, float("nan")):                           # nothing to certify: stays on the direct kernel
         assert check_query(gt, ot, reads, thr, path=1).path == 0
     st = check_query(gt, ot, reads, 1.0, path=1)                   # bucketed: screen + records + LDS-tile certificates
@@ -343,17 +343,43 @@ def test_config2_shape_64_leaves_k21(gpu):
     noisy = seq.copy()
     where = rng.random(noisy.size - 16) < 0.02
     noisy[:-16][where] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(where.sum()))
+    # (PFQ_TILE_COUNTS=1: the LDS-tile passes sort out the pairs with no k-mer missing and the record kernel counts the
+    # rest — chosen on its own only when few pairs miss a k-mer, forced here with most pairs missing some; with a small
+    # entry buffer on top, chunks of passes that were not launched go to the record kernel as well)
     for thr in (0.3, 0.7):
         for v in range(ot.n_nodes):
             ot.mapped_reads[v] = 0
         oh, _, _ = orc.query_batch_packed(ot, noisy, off, thr, threads=8)
+        want = np.array(oracle_hits(ot, oh), dtype=np.int64).reshape(-1, 2)
+        for env in ({}, {"PFQ_TILE_COUNTS": "1"}, {"PFQ_TILE_COUNTS": "1", "PFQ_TILE_ENTRIES": "6000000"}):
+            os.environ.update(env)
+            try:
+                for call in range(2):
+                    gt.reset_counts()
+                    gt.set_path(-1)
+                    offs, leaves = gt.query_packed(noisy, off, thr, want_hits=True)
+                    st = gt.last_stats()
+                    assert st.path == 1 and st.tile_mode == (1 if env else 0)
+                    assert gt.get_leaf_counts() == ot.leaf_counts(), (thr, env, call)
+                    got = np.stack([np.repeat(np.arange(n_reads), np.diff(offs).astype(np.int64)), leaves.astype(np.int64)], 1)
+                    assert np.array_equal(got, want), (thr, env, call)
+            finally:
+                for key in env:
+                    del os.environ[key]
+    # clean reads at a threshold below 1: after one call the tile passes are chosen without being asked for
+    for v in range(ot.n_nodes):
+        ot.mapped_reads[v] = 0
+    oh, _, _ = orc.query_batch_packed(ot, seq, off, 0.5, threads=8)
+    want = np.array(oracle_hits(ot, oh), dtype=np.int64).reshape(-1, 2)
+    modes = []
+    for call in range(3):
         gt.reset_counts()
-        gt.set_path(-1)
-        offs, leaves = gt.query_packed(noisy, off, thr, want_hits=True)
-        assert gt.last_stats().path == 1
-        assert gt.get_leaf_counts() == ot.leaf_counts(), thr
+        offs, leaves = gt.query_packed(seq, off, 0.5, want_hits=True)
+        modes.append(gt.last_stats().tile_mode)
+        assert gt.get_leaf_counts() == ot.leaf_counts(), call
         got = np.stack([np.repeat(np.arange(n_reads), np.diff(offs).astype(np.int64)), leaves.astype(np.int64)], 1)
-        assert np.array_equal(got, np.array(oracle_hits(ot, oh), dtype=np.int64).reshape(-1, 2)), thr
+        assert np.array_equal(got, want), call
+    assert modes[-1] == 1, modes
     for v in range(ot.n_nodes):
         ot.mapped_reads[v] = 0
     orc.query_batch_packed(ot, seq, off, 1.0, threads=8)     # (restore the threshold-1 counts used below)
@@ -674,6 +700,8 @@ def test_randomized_parity(gpu, seed):
     entries = int(rng.choice([0, 0, 30_000, 400_000, 5_000_000]))
     if entries:
         os.environ["PFQ_TILE_ENTRIES"] = str(entries)
+    if seed % 2:
+        os.environ["PFQ_TILE_COUNTS"] = "1"   # thresholds < 1 through the LDS-tile passes whatever the share of clean pairs
     try:
         gt = gpu_tree(genomes, ids, k, nbits, h)
         for thr in (1.0, float(rng.choice([0.05, 0.3, 0.5, 0.9])), float(rng.choice([0.0, 0.2, 0.75, 0.999, 1.5]))):
@@ -682,3 +710,4 @@ def test_randomized_parity(gpu, seed):
         gt.close()
     finally:
         os.environ.pop("PFQ_TILE_ENTRIES", None)
+        os.environ.pop("PFQ_TILE_COUNTS", None)
