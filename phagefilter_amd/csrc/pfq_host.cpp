@@ -115,7 +115,7 @@ struct pfq_tree {
     DevBuf<uint32_t> d_S, d_col_row, d_guard_off, d_guard_col;
     DevBuf<unsigned long long> d_counts;
     // ---- query scratch
-    DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit, [1] pair, [2] tile entries, [3] lo: chunks, hi: flagged pairs, [4] long reads, [5] miss words, [6] dirty pairs, [7] open pairs after the tile passes
+    DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit, [1] pair, [2] tile entries, [3] lo: chunks, hi: flagged pairs, [4] long reads, [5] miss words, [6] dirty pairs, [7] lo: open pairs after the tile passes (thresholds < 1)
     DevBuf<uint32_t> d_entries, d_pair_chunk, d_leaf_chunk0, d_flag_list;  // LDS-tile certificates
     DevBuf<pfq::ChunkDesc> d_chunks;
     DevBuf<unsigned int> d_gfill;
@@ -760,17 +760,16 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                     HIP_TRY(hipEventRecord(ev[3], st));
                     HIP_TRY(hipEventRecord(ev[4], st));
                 }
+                if (v.only_flagged == 1 && counts_mode) {
+                    // thresholds < 1: the list becomes every pair the tile passes left open (a k-mer missing, or not binned)
+                    unsigned int *n_open = reinterpret_cast<unsigned int *>(t.d_cursors.p + 7);
+                    pfq::launch_collect_open(t.d_fail.p, off + nb, t.d_flag_list.p, v.flag_cap, n_open, st);
+                    v.n_flagged = n_open;
+                }
                 pfq::launch_verify(v, vblocks, vthreads, st);
                 if (v.only_flagged == 1) {  // many flagged pairs (no room for their probe buckets): walk all pairs in leaf order instead
                     v.only_flagged = 2;
-                    if (counts_mode) {
-                        // thresholds < 1: the walk is the only launch that works (pairs with a k-mer missing are on no list);
-                        // larger queue items (the walk pulls an item per 64 pairs, not per 8), and none at all when the tile
-                        // passes left no pair open
-                        pfq::launch_count_open(t.d_fail.p, off + nb, t.d_cursors.p + 7, st);
-                        v.n_open = t.d_cursors.p + 7;
-                        v.chunk = 8;
-                    }
+                    if (counts_mode) v.chunk = 8;  // (the walk pulls an item per 64 pairs, not per 8)
                     pfq::launch_verify(v, vblocks, vthreads, st);
                 }
                 if (ev) HIP_TRY(hipEventRecord(ev[5], st));

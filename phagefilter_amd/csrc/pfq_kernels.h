@@ -79,9 +79,6 @@ struct VerifyArgs {
     const unsigned long long *entry_cursor;
     uint64_t entry_cap;
     uint32_t launched_passes;
-    // thresholds < 1 after tile passes: number of pairs whose fail word is non-zero (k_count_open); none and nothing left
-    // over: the scan returns at once
-    const unsigned long long *n_open;
     const unsigned int *n_flagged;  // number of such pairs (kernel returns at once when 0)
     const uint32_t *flag_list;      // their sorted-pair indices
     const uint4 *recs;           // probe records written by k_classify<DEFER> (nullptr: re-hash per slice)
@@ -163,8 +160,8 @@ void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs
                            const uint64_t *read_off, const uint32_t *col_row, const uint32_t *words_off, uint32_t *words_cur,
                            uint32_t *miss_pos, uint32_t kmer_size, int blocks, hipStream_t st);
 void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st);
-// *out += number of sorted pairs with a non-zero fail word
-void launch_count_open(const uint32_t *fail, const uint32_t *n_pairs_ptr, unsigned long long *out, hipStream_t st);
+// list = the sorted pairs with a non-zero fail word, in order within runs; *n_out += their number (thresholds < 1 after tile passes)
+void launch_collect_open(const uint32_t *fail, const uint32_t *n_pairs_ptr, uint32_t *list, uint32_t cap, unsigned int *n_out, hipStream_t st);
 void launch_finalize(const FinalizeArgs &a, hipStream_t st);
 
 void launch_insert(const HashParams &hp, const uint8_t *d_genomes, const uint64_t *d_goff, uint32_t n_genomes,

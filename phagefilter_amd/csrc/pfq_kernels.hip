@@ -861,11 +861,11 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
     if (a.only_flagged) {
         const unsigned int nf = *a.n_flagged;
         leftover = a.entry_cursor && *a.entry_cursor > (unsigned long long)a.launched_passes * a.entry_cap;
-        const bool many = (uint64_t)nf * 16u > (uint64_t)*a.n_pairs_ptr || nf > a.flag_cap;
-        // thresholds < 1 after the tile passes: the pairs with a k-mer missing (bit 0) are not on the list, so scan
-        const bool scan = many || leftover || a.miss_words != nullptr;
+        // (thresholds < 1: the list is k_collect_open's — every pair with a non-zero fail word, in sorted order — and is
+        // used whatever its length: a walk over all pairs leaves most waves of an item idle when few pairs are open)
+        const bool many = a.miss_words ? nf > a.flag_cap : ((uint64_t)nf * 16u > (uint64_t)*a.n_pairs_ptr || nf > a.flag_cap);
+        const bool scan = many || leftover;
         if (a.only_flagged == 1 ? (nf == 0 || scan) : !scan) return;
-        if (a.miss_words && a.n_open && *a.n_open == 0 && !leftover) return;  // every pair certified clean by the tile passes
     }
     const bool from_list = a.only_flagged == 1, skip_certified = a.only_flagged == 2;
     const uint64_t n_pairs = from_list ? *a.n_flagged : *a.n_pairs_ptr;
@@ -1378,15 +1378,48 @@ void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_tile_test, dim3((blocks + 1) / 2), dim3(1024), (size_t)(1u << (TILE_LOG2 - 3)), st, a);
 }
 
-__global__ void __launch_bounds__(256) k_count_open(const uint32_t *fail, const uint32_t *n_pairs_ptr, unsigned long long *out) {
-    const uint32_t n = *n_pairs_ptr;
+// Thresholds < 1 after the tile passes: the compact list of the pairs whose fail word is non-zero (a probe found 0, or the
+// pair could not be binned).  Every block takes one contiguous range of the sorted pairs and appends its open pairs in
+// order, so the list stays leaf-ordered in runs of thousands of pairs (the slices stay L2-resident for k_verify_rec).
+__global__ void __launch_bounds__(256) k_collect_open(const uint32_t *fail, const uint32_t *n_pairs_ptr, uint32_t *list,
+                                                      uint32_t cap, unsigned int *n_out) {
+    __shared__ uint32_t s_w[4], s_base;
+    const uint32_t n = *n_pairs_ptr, lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t per = ((n + gridDim.x - 1) / gridDim.x + 255u) & ~255u;
+    const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    if (lo >= n) return;  // (block-uniform)
     uint32_t c = 0;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) c += fail[e] != 0u;
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += 256) c += fail[e] != 0u;
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
-    if (lane_id() == 0 && c) atomicAdd(out, (unsigned long long)c);
+    if (lane == 0) s_w[wave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        s_base = tot ? atomicAdd(n_out, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t run = s_base;
+    if (s_w[0] + s_w[1] + s_w[2] + s_w[3] == 0) return;  // (block-uniform)
+    __syncthreads();
+    for (uint32_t e0 = lo; e0 < hi; e0 += 256) {
+        const uint32_t e = e0 + threadIdx.x;
+        const bool open = e < hi && fail[e] != 0u;
+        const uint64_t b = ballot64(open);
+        if (lane == 0) s_w[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 4; ++w) {
+            before += w < wave ? s_w[w] : 0u;
+            all += s_w[w];
+        }
+        const uint32_t pos = run + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (open && pos < cap) list[pos] = e;
+        run += all;
+        __syncthreads();
+    }
 }
-void launch_count_open(const uint32_t *fail, const uint32_t *n_pairs_ptr, unsigned long long *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_count_open, dim3(512), dim3(256), 0, st, fail, n_pairs_ptr, out);
+void launch_collect_open(const uint32_t *fail, const uint32_t *n_pairs_ptr, uint32_t *list, uint32_t cap, unsigned int *n_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_collect_open, dim3(512), dim3(256), 0, st, fail, n_pairs_ptr, list, cap, n_out);
 }
 void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st) {
     if (a.recs) hipLaunchKernelGGL(k_verify_rec, dim3(blocks), dim3(threads), 0, st, a);
