@@ -667,7 +667,7 @@ def test_page_locked_host_buffers(gpu):
 # buffer size goes through the same comparison with the oracle (per-leaf counts and every per-read hit set)
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(10)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("PFQ_PARITY_SEEDS", "10")))))   # (soak runs: more seeds)
 def test_randomized_parity(gpu, seed):
     rng = np.random.default_rng(1000 + seed)
     n_genomes = int(rng.choice([3, 17, 40, 130, 290, 520, 1040]))
