@@ -287,8 +287,8 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
 // Here a wave screens 64/lpr consecutive reads at once, lpr = rw/4 lanes per read: lane (j, q) hashes k-mer
 // pos+q of read j and owns dwords 4q..4q+3 (128 leaf columns) of every row of that read, so the vertical counters
 // never cross lanes; each pass issues lpr row gathers of 16 bytes per lane before any is consumed.  Needs
-// 16 <= rw <= 64 and reads of fewer than 2^P k-mers (P counter planes: 8 in the main launch, 16 in the launch for
-// long reads); other reads are returned in `irregular` for the per-read path.  The group is reads r0 .. r0+n-1, or
+// 16 <= rw <= 64 and reads that may miss fewer than 2^P k-mers (n - need < 2^P; P counter planes: 8 in the main launch,
+// 16 in the launch for long reads); other reads are returned in `irregular` for the per-read path.  The group is reads r0 .. r0+n-1, or
 // list[r0 .. r0+n-1] when a list is given; `rid` returns the lane's read.  On return live_out[j*rw + w] holds the
 // frontier words of read j and `survive` the reads with a non-empty frontier.
 template <uint32_t P>
@@ -309,7 +309,9 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
     const uint64_t n64 = (L >= k) ? (L - k + 1) : 0;
     const uint64_t need = need_kmers(a.threshold, n64);
     const bool in_group = j < n_in_group;
-    const bool regular = in_group && n64 >= 1 && n64 < (1ull << P) && need >= 1 && need <= n64;
+    // (the counters only have to reach maxmiss + 1: reads of any length whose n - need fits P bits are regular, e.g.
+    // 300 bp at theta 0.5 with 8 planes)
+    const bool regular = in_group && n64 >= 1 && n64 < (1ull << 31) && need >= 1 && need <= n64 && n64 - need < (1ull << P);
     const uint32_t n = regular ? (uint32_t)n64 : 0u, maxmiss = regular ? (uint32_t)(n64 - need) : 0u;
     irregular = 0;
     {
