@@ -157,7 +157,8 @@ typedef struct pfq_stats {
     uint64_t algorithmic_bytes; /* sum_r L(r) + |hits(r)| * need(r) * num_hashes * 32 */
     uint32_t path;              /* 0 = direct kernel, 1 = bucketed (screen + L2-sliced verify) */
     uint32_t n_slices;
-    uint32_t tile_mode;         /* 1: certificates tested out of LDS tiles (k_tile_*), k_verify_rec only as fallback */
+    uint32_t tile_mode;         /* 1: certificates tested out of LDS tiles (k_tile_*), k_verify_rec only as fallback
+                                 * (thresholds < 1: the tiles certify the pairs with no k-mer missing, k_verify_rec counts the rest) */
     uint32_t n_fallback_pairs;  /* pairs the LDS-tile pass could not bin (certified by the fallback kernel) */
     uint64_t n_chunks, tile_entries;
     uint32_t tile_passes_launched, tile_passes_needed;  /* LDS-tile stage: passes over the reused probe buckets */
