@@ -322,18 +322,19 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
             irregular |= 1u << ((uint32_t)l >> lpr_log2);
         }
     }
-    // cm: leaf columns of my four dwords; dead: leaves whose miss count exceeded maxmiss.  The counters start at
+    // dead: leaves (of my four dwords) whose miss count exceeded maxmiss.  The counters start at
     // 2^P - 1 - maxmiss, so "misses > maxmiss" is the carry out of the top plane: no comparison is needed, and rows
     // need no masking either (counters of dead leaves and of padding columns may wrap, they stay dead).
-    uint32_t cm[4], dead[4];
+    // (columns that are no leaves start out dead: no separate column mask has to stay in registers)
+    uint32_t dead[4];
     const uint32_t bias = regular ? ((1u << P) - 1u - maxmiss) : 0u;
     uint32_t c[P][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const uint32_t w = q * 4u + u;
-        cm[u] = (w * 32u < a.n_leaves) ? ((a.n_leaves - w * 32u >= 32u) ? ~0u : ((1u << (a.n_leaves - w * 32u)) - 1u)) : 0u;
-        if (!regular) cm[u] = 0u;
-        dead[u] = 0u;
+        uint32_t cmu = (w * 32u < a.n_leaves) ? ((a.n_leaves - w * 32u >= 32u) ? ~0u : ((1u << (a.n_leaves - w * 32u)) - 1u)) : 0u;
+        if (!regular) cmu = 0u;
+        dead[u] = ~cmu;
 #pragma unroll
         for (uint32_t p = 0; p < P; ++p) c[p][u] = ((bias >> p) & 1u) ? ~0u : 0u;
     }
@@ -406,13 +407,13 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
             PFQ_CSA_WORD(w, 3)
 #undef PFQ_CSA_WORD
         }
-        uint32_t any = (cm[0] & ~dead[0]) | (cm[1] & ~dead[1]) | (cm[2] & ~dead[2]) | (cm[3] & ~dead[3]);
+        uint32_t any = ~(dead[0] & dead[1] & dead[2] & dead[3]);
         for (uint32_t sft = 1; sft < lpr; sft <<= 1) any |= (uint32_t)__shfl_xor((int)any, (int)sft);
         alive = alive && any != 0;
     }
     uint32_t live[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) live[u] = cm[u] & ~dead[u];
+    for (int u = 0; u < 4; ++u) live[u] = ~dead[u];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < 4; ++u) live_out[j * rw + q * 4u + u] = live[u];
