@@ -662,6 +662,44 @@ def test_page_locked_host_buffers(gpu):
     gt.close()
 
 
+@pytest.mark.gpu
+def test_async_host_blocks_thresholds_below_one(gpu):
+    """Block loop of the CLI: pfq_query_batch without PFQ_WANT_HITS returns before the kernels ran, blocks follow each
+    other through the two input buffers, and the sizing hints of one call (pairs per read, share of pairs with a k-mer
+    missing) steer the next.  Counts after the loop equal the oracle's over all reads, at thresholds below 1 too."""
+    import ctypes as C
+    from phagefilter_amd import _ffi
+    n_g, glen, k, h, nbits = 64, 3000, 21, 10, 4000037
+    genomes_np = np.stack([np.frombuffer(orc.synth_genome(0xABC0000 + i, glen), dtype=np.uint8) for i in range(n_g)])
+    genomes = [g.tobytes() for g in genomes_np]
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    gt = gpu_tree(genomes, ids, k, nbits, h)
+    gt.set_path(1)
+    L = _ffi.lib()
+    n_blocks, per = 4, 30000
+    reads_np = orc.synth_reads(0x77771234, 0, n_blocks * per, 150, genomes_np, glen)
+    rng = np.random.default_rng(5)
+    for thr, err in ((0.5, 0.0), (0.3, 0.02), (1.0, 0.0)):
+        data = reads_np.copy().reshape(-1)
+        if err:
+            where = rng.random(data.size) < err
+            data[where] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(where.sum()))
+        seq = np.concatenate([data, np.zeros(16, dtype=np.uint8)])
+        off = np.arange(n_blocks * per + 1, dtype=np.uint64) * 150
+        for v in range(ot.n_nodes):
+            ot.mapped_reads[v] = 0
+        orc.query_batch_packed(ot, seq, off, thr, threads=8)
+        gt.reset_counts()
+        for b in range(n_blocks):   # (nothing in the loop waits for the device)
+            bseq = np.ascontiguousarray(seq[b * per * 150:(b + 1) * per * 150 + 16])
+            boff = np.arange(per + 1, dtype=np.uint64) * 150
+            _ffi.check(L.pfq_query_batch(gt._h, bseq.ctypes.data_as(C.c_void_p), boff.ctypes.data_as(C.c_void_p), per,
+                                         C.c_float(thr), 0, None))
+        assert gt.get_leaf_counts() == ot.leaf_counts(), (thr, err)
+        assert gt.last_stats().path == 1
+    gt.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # randomized configurations: every combination of tree width, read-length mix, threshold, query path and bucket
 # buffer size goes through the same comparison with the oracle (per-leaf counts and every per-read hit set)
