@@ -3,7 +3,7 @@ GPU box: SURVEY §8f rows 1-2.  Builds a balanced 64-leaf database of the BASELI
 synthetic 150 bp FASTQ (50 % positive) and times the CLI for several worker counts, with and without POS/NEG output
 and from gzip.  Prints one JSON line per run.
 
-    python tools/cli_bench.py [--reads 16000000] [--threads 1,4,16] [--workdir /tmp/pfq_cli_bench]
+    python tools/cli_bench.py [--reads 16000000] [--threads 1,4,16] [--threshold 1.0] [--block 100000] [--workdir /tmp/pfq_cli_bench]
 """
 import argparse
 import gzip
@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--threads", default="1,4,16")
     ap.add_argument("--workdir", default="/tmp/pfq_cli_bench")
     ap.add_argument("--leaves", type=int, default=64)
+    ap.add_argument("--threshold", default="1.0", help="-f of every query run")
+    ap.add_argument("--block", default="100000", help="-b of every query run")
     a = ap.parse_args()
     import torch
     from phagefilter_amd import BloomTree, _ffi
@@ -91,7 +93,7 @@ def main():
         out = os.path.join(a.workdir, "out")
         env = dict(os.environ, PFQ_INGEST_TIMING="1")
         t0 = time.time()
-        p = subprocess.run([CLI, "query", "-r", reads_path, "-o", out, "-d", db, "-t", str(threads), "-b", "100000", *extra],
+        p = subprocess.run([CLI, "query", "-r", reads_path, "-o", out, "-d", db, "-t", str(threads), "-b", a.block, "-f", a.threshold, *extra],
                            capture_output=True, text=True, env=env)
         wall = time.time() - t0
         assert p.returncode == 0, p.stderr
