@@ -705,7 +705,8 @@ def test_async_host_blocks_thresholds_below_one(gpu):
 # buffer size goes through the same comparison with the oracle (per-leaf counts and every per-read hit set)
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("PFQ_PARITY_SEEDS", "10")))))   # (soak runs: more seeds)
+@pytest.mark.parametrize("seed", [int(os.environ.get("PFQ_PARITY_SEED0", "0")) + i
+                                  for i in range(int(os.environ.get("PFQ_PARITY_SEEDS", "10")))])   # (soak runs: more seeds)
 def test_randomized_parity(gpu, seed):
     rng = np.random.default_rng(1000 + seed)
     n_genomes = int(rng.choice([3, 17, 40, 130, 290, 520, 1040]))
