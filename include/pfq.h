@@ -106,6 +106,16 @@ int pfq_tree_build_balanced_device(const uint8_t *d_genomes, uint64_t genome_len
                                    uint32_t num_hashes, uint64_t seed1, uint64_t seed2, float false_pos_rate,
                                    uint32_t largest_expected_genome, int device, pfq_tree **out);
 
+/* One subtree shard of that synthetic tree without ever holding the whole tree (BASELINE config 5: 16 384 leaves =
+ * 294 GB of filters, one 2048-leaf shard per GPU): the same topology and names as pfq_tree_build_balanced_device over all
+ * n_genomes, reduced like pfq_tree_open_subtree(depth, index); the shard's subtree is built from its own genomes and every
+ * ancestor on the chain holds the union of ALL genomes below it in the whole tree.  d_genomes: all n_genomes genomes. */
+int pfq_tree_build_balanced_subtree_device(const uint8_t *d_genomes, uint64_t genome_len, uint64_t n_genomes,
+                                           const char *const *tax_ids, uint64_t kmer_size, uint64_t nbits,
+                                           uint32_t num_hashes, uint64_t seed1, uint64_t seed2, float false_pos_rate,
+                                           uint32_t largest_expected_genome, uint64_t depth, uint64_t index, int device,
+                                           pfq_tree **out);
+
 /* BloomTree::save (bloom_tree.rs:339-355) + the .bf files BloomFilter::save_to_file writes
  * (bloom_filter.rs:176-205), so the reference binary can open a tree built here. */
 int pfq_tree_save(const pfq_tree *tree, const char *db_dir);
@@ -149,13 +159,29 @@ int pfq_leaf_counts_export(pfq_tree *tree, uint64_t *d_dst, void *stream);
 int pfq_leaf_counts_import(pfq_tree *tree, const uint64_t *d_src, void *stream);
 int pfq_leaf_counts_reset(pfq_tree *tree);
 
+/* Several GPUs behind one process (the block loop of main.rs:334-368 dealt over devices): `trees` are replicas of one
+ * database (pfq_tree_open of the same directory, same pruning) on any devices, each fed its own share of the reads by its
+ * own host thread.  This sums their per-leaf counters so that afterwards EVERY replica holds the job's totals
+ * (mapped_reads of query.rs:143 as if one tree had seen all reads): replicas that share a device are added on that device,
+ * then ONE ncclAllReduce(sum, uint64, n_leaves) over RCCL / xGMI runs across the distinct devices (8 KiB at 1024 leaves).
+ * Waits for the replicas' queued work.  librccl is loaded when this is first called with more than one replica. */
+int pfq_trees_allreduce_counts(pfq_tree *const *trees, uint32_t n_trees);
+/* Number of RCCL ranks the last pfq_trees_allreduce_counts on this thread used (0: no communicator was needed). */
+uint32_t pfq_last_allreduce_ranks(void);
+
 /* ---- measurement / test hooks ---- */
+
+/* Tuning / test knobs, e.g. ("PFQ_TILE", "0").  The PFQ_* environment variables of the same names are
+ * read once, when a tree is created or opened; this changes one knob of one tree afterwards.  value NULL or "": back
+ * to the built-in choice.  Results never depend on a knob. */
+int pfq_set_option(pfq_tree *tree, const char *name, const char *value);
+
 
 /* Per-call statistics of the last pfq_query_batch[_device] (valid after the stream is synchronised). */
 typedef struct pfq_stats {
     uint64_t n_reads, n_candidates, n_hits, n_allhit_reads;
     uint64_t algorithmic_bytes; /* sum_r L(r) + |hits(r)| * need(r) * num_hashes * 32 */
-    uint32_t path;              /* 0 = direct kernel, 1 = bucketed (screen + L2-sliced verify) */
+    uint32_t path;              /* 0 = direct kernel, 1 = bucketed (screen, pairs sorted by leaf, certificates out of LDS tiles / L2 slices) */
     uint32_t n_slices;
     uint32_t tile_mode;         /* 1: certificates tested out of LDS tiles (k_tile_*), k_verify_rec only as fallback
                                  * (thresholds < 1: the tiles certify the pairs with no k-mer missing, k_verify_rec counts the rest) */

@@ -310,6 +310,48 @@ def build_balanced_tree(genomes: Sequence[bytes], tax_ids: Sequence[str], kmer_s
     return t
 
 
+def subtree_shard(t: OracleTree, depth: int, index: int):
+    """Subtree shard of a tree (BASELINE config 5; the rule of pfq_tree_open_subtree in include/pfq.h): the shards are
+    the nodes of the depth-`depth` frontier left to right (nodes at that depth, plus leaves above it); shard `index`
+    keeps that node, everything below it and the chain of its ancestors, each reduced to the child on the path.
+    Returns (shard tree sharing `t.bits`, position of its first leaf in the whole tree's leaf order); the reference's
+    DFS (query.rs:99-158) over the shard visits the ancestors first, exactly as it would in the whole tree."""
+    import copy
+    frontier, parent = [], {t.root: -1}
+    stack = [(t.root, 0)]
+    while stack:
+        v, d = stack.pop()
+        if d == depth or t.is_leaf(v):
+            frontier.append(v)
+            continue
+        for c in (t.right[v], t.left[v]):
+            if c >= 0:
+                parent[c] = v
+                stack.append((c, d + 1))
+    if not 0 <= index < len(frontier):
+        raise IndexError(f"subtree index {index} out of range: the depth-{depth} frontier has {len(frontier)} nodes")
+
+    def n_leaves(root: int) -> int:
+        n, st = 0, [root]
+        while st:
+            v = st.pop()
+            n += t.is_leaf(v)
+            st += [c for c in (t.left[v], t.right[v]) if c >= 0]
+        return n
+
+    first = sum(n_leaves(f) for f in frontier[:index])
+    sh = copy.copy(t)                       # arrays below are replaced; `bits` stays shared
+    sh.left, sh.right, sh.mapped_reads = list(t.left), list(t.right), [0] * t.n_nodes
+    c, v = frontier[index], parent[frontier[index]]
+    while v >= 0:
+        if sh.left[v] != c:
+            sh.left[v] = -1
+        if sh.right[v] != c:
+            sh.right[v] = -1
+        c, v = v, parent[v]
+    return sh, first
+
+
 def renumber_preorder(t: OracleTree) -> None:
     """Nodes in pre-order (root = 0) again; filter rows stay where they are."""
     order: List[int] = []

@@ -10,7 +10,8 @@ LIB_PATH = os.path.join(_HERE, "libpfq.so")
 
 # every symbol include/pfq.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "pfq_tree_open", "pfq_tree_open_subtree", "pfq_tree_create", "pfq_tree_insert", "pfq_tree_build_balanced", "pfq_tree_build_balanced_device", "pfq_tree_save", "pfq_tree_info",
+    "pfq_tree_open", "pfq_tree_open_subtree", "pfq_tree_create", "pfq_tree_insert", "pfq_tree_build_balanced", "pfq_tree_build_balanced_device",
+    "pfq_tree_build_balanced_subtree_device", "pfq_trees_allreduce_counts", "pfq_last_allreduce_ranks", "pfq_set_option", "pfq_tree_save", "pfq_tree_info",
     "pfq_tree_prune", "pfq_tree_close", "pfq_query_batch", "pfq_query_batch_device", "pfq_leaf_counts",
     "pfq_save_leaf_counts", "pfq_leaf_counts_export", "pfq_leaf_counts_import", "pfq_leaf_counts_reset",
     "pfq_last_stats", "pfq_set_path", "pfq_profile_begin", "pfq_profile_end", "pfq_debug_kmer_indices", "pfq_debug_node_filter", "pfq_synth_genomes_device",
@@ -72,6 +73,12 @@ def lib() -> C.CDLL:
     L.pfq_tree_build_balanced_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_char_p), C.c_uint64,
                                                  C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_float, C.c_uint32,
                                                  C.c_int, C.POINTER(vp)]
+    L.pfq_tree_build_balanced_subtree_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_char_p), C.c_uint64,
+                                                         C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_float, C.c_uint32,
+                                                         C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]
+    L.pfq_trees_allreduce_counts.argtypes = [C.POINTER(vp), C.c_uint32]
+    L.pfq_last_allreduce_ranks.restype = C.c_uint32
+    L.pfq_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.pfq_tree_create.argtypes = [C.c_uint64, C.c_float, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]
     L.pfq_tree_insert.argtypes = [vp, vp, C.c_uint64, C.c_char_p, C.c_char_p]
     L.pfq_host_alloc.argtypes = [C.c_uint64, C.POINTER(vp)]
@@ -104,3 +111,19 @@ def lib() -> C.CDLL:
 def check(rc: int) -> None:
     if rc != 0:
         raise PfqError(rc, lib().pfq_last_error().decode(errors="replace"))
+
+
+def source_stamp() -> str:
+    """sha256 over the sources of libpfq (csrc/*.hip, *.cpp, *.h + include/pfq.h): stamps measurements that are taken in a
+    separate pass (profiles/pmc_traffic.json) so that bench.py can tell whether they still describe the code it runs."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) +
+                   glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(os.path.dirname(_HERE), "include", "pfq.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

@@ -4,6 +4,8 @@
 // Compiled with hipcc together with pfq_kernels.hip.  No CPU compute path exists here: all filter work is
 // done by the kernels and every entry point fails with PFQ_ERR_DEVICE when no gfx950 device is usable.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is loaded when pfq_trees_allreduce_counts first needs it
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <thread>
@@ -73,10 +75,47 @@ struct DevBuf {
     size_t bytes() const { return n * sizeof(T); }
 };
 
+// Tuning / test knobs.  Never needed for correct results.  The environment is read ONCE, when a tree is
+// created or opened; afterwards pfq_set_option changes a knob of that tree.  -1 / unset = the built-in choice.
+struct Knobs {
+    long long record_gb = -1, tile_gb = -1, tile_entries = -1, slice_kb = -1;
+    long long verify_blocks = -1, verify_chunk = -1, verify_sub = -1, verify_threads = -1, bin_blocks = -1, test_blocks = -1;
+    long long tile = -1, tile_counts = -1, no_tail_batch = -1, bin_narrow = -1, bin_wide = -1;
+};
+struct KnobName {
+    const char *name;
+    long long Knobs::*field;
+};
+const KnobName KNOBS[] = {
+    {"PFQ_RECORD_GB", &Knobs::record_gb},       {"PFQ_TILE_GB", &Knobs::tile_gb},
+    {"PFQ_TILE_ENTRIES", &Knobs::tile_entries}, {"PFQ_SLICE_KB", &Knobs::slice_kb},
+    {"PFQ_VERIFY_BLOCKS", &Knobs::verify_blocks}, {"PFQ_VERIFY_CHUNK", &Knobs::verify_chunk},
+    {"PFQ_VERIFY_SUB", &Knobs::verify_sub},     {"PFQ_VERIFY_THREADS", &Knobs::verify_threads},
+    {"PFQ_BIN_BLOCKS", &Knobs::bin_blocks},     {"PFQ_TEST_BLOCKS", &Knobs::test_blocks},
+    {"PFQ_TILE", &Knobs::tile},                 {"PFQ_TILE_COUNTS", &Knobs::tile_counts},
+    {"PFQ_NO_TAIL_BATCH", &Knobs::no_tail_batch}, {"PFQ_BIN_NARROW", &Knobs::bin_narrow},
+    {"PFQ_BIN_WIDE", &Knobs::bin_wide},
+};
+bool set_knob(Knobs &k, const char *name, const char *value) {
+    for (const KnobName &kn : KNOBS)
+        if (!strcmp(kn.name, name)) {
+            k.*(kn.field) = (value && *value) ? strtoll(value, nullptr, 10) : -1;
+            return true;
+        }
+    return false;
+}
+Knobs knobs_from_env() {
+    Knobs k;
+    for (const KnobName &kn : KNOBS)
+        if (const char *e = getenv(kn.name)) set_knob(k, kn.name, e);
+    return k;
+}
+
 }  // namespace
 
 struct pfq_tree {
     int device = 0;
+    Knobs knobs = knobs_from_env();
     // ---- model
     std::vector<Node> nodes;  // pre-order, root = 0
     int32_t root = -1;
@@ -112,7 +151,10 @@ struct pfq_tree {
     std::vector<uint32_t> col_row;   // column -> filter row
     std::vector<uint32_t> guard_off, guard_col;
     uint32_t rw = 1, rw_log2 = 0, n_cols = 0;
+    uint32_t n_groups = 1;           // column groups of the sliced matrix (2048 columns each when there are several)
+    uint64_t group_stride = 0;       // dwords per group: (n_words * 64 + 1) * rw
     DevBuf<uint32_t> d_S, d_col_row, d_guard_off, d_guard_col;
+    DevBuf<uint32_t> d_owner, d_owner_sorted, d_gfail;  // trees with guard columns, bucketed path: leaf pair of every pair slot
     DevBuf<unsigned long long> d_counts;
     // ---- query scratch
     DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit, [1] pair, [2] tile entries, [3] lo: chunks, hi: flagged pairs, [4] long reads, [5] miss words, [6] dirty pairs, [7] lo: open pairs after the tile passes (thresholds < 1)
@@ -441,19 +483,24 @@ int build_layout(pfq_tree &t) {
     uint32_t need_words = std::max<uint32_t>(1, (t.n_cols + 31) / 32);
     t.rw = 4;  // at least 16-byte rows: the dense pre-screen gathers rows with dwordx4 loads
     t.rw_log2 = 2;
-    while (t.rw < need_words) {
+    while (t.rw < need_words && t.rw < 64) {
         t.rw <<= 1;
         ++t.rw_log2;
     }
-    if (t.rw > 64)
-        return fail(PFQ_ERR_UNSUPPORTED, "tree has " + std::to_string(t.n_cols) +
-                                             " leaf+guard columns; this build supports at most 2048 (DESIGN.md §6)");
+    // a wave holds one row of up to 64 dwords (2048 columns) across its lanes; wider trees are cut into column groups of
+    // 2048, each with a sliced matrix of its own, and the frontier kernels run once per group
+    t.n_groups = std::max<uint32_t>(1, (t.n_cols + 2047) / 2048);
+    t.group_stride = ((uint64_t)t.n_words * 64 + 1) * t.rw;  // + the all-ones row of the group
     if (nl == 0) {
         t.layout_valid = true;
         return PFQ_OK;
     }
-    const size_t s_words = (size_t)t.n_words * 64 * t.rw;
-    HIP_TRY(t.d_S.ensure(s_words + t.rw));  // + the all-ones row
+    const size_t s_words = (size_t)t.group_stride * t.n_groups;
+    if (t.d_S.ensure(s_words) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(PFQ_ERR_DEVICE, "not enough device memory for the sliced matrix of " + std::to_string(t.n_cols) +
+                                        " leaf+guard columns (" + std::to_string(s_words * 4 >> 20) + " MiB)");
+    }
     HIP_TRY(t.d_col_row.ensure(t.col_row.size()));
     HIP_TRY(t.d_guard_off.ensure(t.guard_off.size() + t.n_cols));  // guard lists are indexed by column; pad for guard columns
     HIP_TRY(t.d_guard_col.ensure(std::max<size_t>(1, t.guard_col.size())));
@@ -466,8 +513,9 @@ int build_layout(pfq_tree &t) {
     for (size_t i = 0; i < nl; ++i) h[i] = t.nodes[t.leaves[i]].mapped_reads;
     HIP_TRY(hipMemcpy(t.d_counts.p, h.data(), nl * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(t.d_S.p, 0, s_words * 4, nullptr));
-    HIP_TRY(hipMemsetAsync(t.d_S.p + s_words, 0xff, t.rw * 4, nullptr));
-    pfq::launch_transpose(t.d_bits.p, t.n_words, t.d_col_row.p, t.n_cols, t.d_S.p, t.rw, nullptr);
+    for (uint32_t g = 0; g < t.n_groups; ++g)
+        HIP_TRY(hipMemsetAsync(t.d_S.p + (g + 1) * t.group_stride - t.rw, 0xff, t.rw * 4, nullptr));
+    pfq::launch_transpose(t.d_bits.p, t.n_words, t.d_col_row.p, t.n_cols, t.d_S.p, t.rw, t.group_stride, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     t.layout_valid = true;
@@ -488,11 +536,24 @@ int ensure_scratch(pfq_tree &t, uint64_t n_reads, bool want_hits) {
 }
 constexpr uint64_t CLASSIFY_MAX_BLOCKS = 4096;  // blocks of 4 waves; every wave may leave one reservation partly used
 
-int ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads) {
+// An allocation that may fail without failing the call: the caller then takes the next exact path.
+template <typename T>
+bool soft_ensure(DevBuf<T> &b, size_t want) {
+    if (b.ensure(want) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
+// Scratch of the bucketed path.  false: not enough device memory, the caller stays on the direct kernel.
+bool ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads, bool with_guards) {
     if (!t.h_pair_cursor) {
-        HIP_TRY(hipHostMalloc((void **)&t.h_pair_cursor, 64, hipHostMallocDefault));
+        if (hipHostMalloc((void **)&t.h_pair_cursor, 64, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            t.h_pair_cursor = nullptr;
+            return false;
+        }
         for (int i = 0; i < 8; ++i) t.h_pair_cursor[i] = 0;
-        HIP_TRY(hipEventCreateWithFlags(&t.hint_ev, hipEventDisableTiming));
+        if (hipEventCreateWithFlags(&t.hint_ev, hipEventDisableTiming) != hipSuccess) return false;
     } else if (t.hint_reads && hipEventQuery(t.hint_ev) == hipSuccess) {
         t.pairs_per_read = std::max(t.pairs_per_read, (double)t.h_pair_cursor[0] / (double)t.hint_reads);
         if (t.hint_entry_cap) t.passes_hint = std::max<uint64_t>(1, (t.h_pair_cursor[1] + t.hint_entry_cap - 1) / t.hint_entry_cap);
@@ -504,12 +565,12 @@ int ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads) {
     // + one partially used reservation per wave.  Pairs that do not fit are certified inline (exact, slow).
     const double per_read = std::min(24.0, std::max(2.0, 1.3 * t.pairs_per_read));
     const uint64_t cap = (uint64_t)(per_read * (double)n_reads) + 32 * 4 * CLASSIFY_MAX_BLOCKS + 1024;
-    HIP_TRY(t.d_pairs.ensure(cap));
-    HIP_TRY(t.d_sorted.ensure(cap));
-    HIP_TRY(t.d_fail.ensure(cap));
-    HIP_TRY(t.d_bucket.ensure(3 * (t.leaves.size() << 6) + 2));  // up to 64 sub-buckets per leaf
-    HIP_TRY(t.d_queue.ensure(128));
-    return PFQ_OK;
+    bool ok = soft_ensure(t.d_pairs, cap) && soft_ensure(t.d_sorted, cap) && soft_ensure(t.d_fail, cap) &&
+              soft_ensure(t.d_bucket, 3 * ((size_t)t.n_cols << 6) + 2) &&  // up to 64 sub-buckets per column
+              soft_ensure(t.d_queue, 128);
+    if (ok && with_guards)
+        ok = soft_ensure(t.d_owner, t.d_pairs.n) && soft_ensure(t.d_owner_sorted, t.d_pairs.n) && soft_ensure(t.d_gfail, t.d_pairs.n);
+    return ok;
 }
 
 constexpr int PROF_EV = 7;  // start, classify, bucket, plan+bin, test, verify, finalize
@@ -529,16 +590,42 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     t.have_last_stream = true;
     t.last_n_reads = n_reads;
     PFQ_TRY(ensure_scratch(t, n_reads, want_hits));
-    const size_t nl = t.leaves.size();
+    const size_t nl = t.leaves.size(), nc = t.n_cols;  // leaf columns; leaf + guard columns (= buckets of the bucketed path)
+    const bool with_guards = !t.guard_col.empty();
     // bucketed path: threshold 1 (any certificate kernel), or 0 < threshold < 1 with probe records (per-pair k-mer miss bits)
     const bool thr_one = threshold == 1.0f, thr_frac = threshold > 0.0f && threshold < 1.0f;
-    uint64_t rec_budget = 64ull << 30;
-    if (const char *e = getenv("PFQ_RECORD_GB")) rec_budget = strtoull(e, nullptr, 10) << 30;
-    const bool recs_possible = total_bytes && t.nbits < (1ull << 30) && t.num_hashes <= 35 && total_bytes * 16 <= rec_budget;
+    const Knobs &kn = t.knobs;
+    // budgets of the two large scratch buffers: what the device can still give (plus what the tree already holds of it),
+    // at most 64 GB each, unless a knob says otherwise; a failed allocation degrades to the next exact path below
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = 0; }
+    uint64_t rec_budget = std::min<uint64_t>(64ull << 30, (uint64_t)((double)(mem_free + t.d_recs.bytes()) * 0.45));
+    if (kn.record_gb >= 0) rec_budget = (uint64_t)kn.record_gb << 30;
+    bool recs_possible = total_bytes && t.nbits < (1ull << 30) && t.num_hashes <= 35 && total_bytes * 16 <= rec_budget;
     // (or as many bases as 2^18 reads of 150 bp: long reads bring the same certificate work with fewer reads)
     bool bucketed = (t.force_path == 1) || (t.force_path < 0 && (n_reads >= BUCKET_MIN_READS || total_bytes >= BUCKET_MIN_READS * 150));
-    if (!(thr_one || (thr_frac && recs_possible)) || !t.guard_col.empty() || nl == 0) bucketed = false;
-    if (bucketed) PFQ_TRY(ensure_bucket_scratch(t, n_reads));
+    if (!(thr_one || thr_frac) || nl == 0 || n_reads == 0) bucketed = false;
+    // probe records: hash survivors once instead of once per slice (needs d < 2^30, <= 35 hashes, room)
+    if (bucketed && recs_possible && !soft_ensure(t.d_recs, total_bytes + 64)) recs_possible = false;
+    if (bucketed && thr_frac && !recs_possible) bucketed = false;  // the miss bits of thresholds < 1 come from the records
+    if (bucketed && !ensure_bucket_scratch(t, n_reads, with_guards)) bucketed = false;
+    if (bucketed && recs_possible && !soft_ensure(t.d_meta, t.d_pairs.n)) recs_possible = false;
+    if (bucketed && thr_frac && !recs_possible) bucketed = false;
+    const bool counts_mode = !(threshold >= 1.0f);  // theta >= 1: need >= n for every read with k-mers
+    uint64_t miss_cap = 0;
+    size_t nb = 0;
+    uint32_t sub_log2 = 0;
+    if (bucketed) {
+        // sub-buckets (keyed by the read index) keep every histogram counter cold when columns are few
+        while (sub_log2 < 6 && (nc << sub_log2) < 1024) ++sub_log2;
+        nb = nc << sub_log2;
+        if (counts_mode) {  // thresholds < 1: every deferred pair owns ceil(n/64) words of k-mer miss bits that the slices OR into
+            const uint64_t avg_len = n_reads ? total_bytes / n_reads : 0;
+            miss_cap = std::min<uint64_t>((t.d_pairs.n & ~31ull) * ((avg_len >> 6) + 2) + 4 * CLASSIFY_MAX_BLOCKS * 1024ull, 0xfffffff0ull);
+            if (!(soft_ensure(t.d_miss_words, miss_cap) && soft_ensure(t.d_miss_pos, t.d_pairs.n) && soft_ensure(t.d_bucket_w, 3 * nb + 2)))
+                bucketed = false;
+        }
+    }
     t.last_path = bucketed ? 1 : 0;
 
     uint64_t hit_cap = t.d_hit_pairs.n;
@@ -557,11 +644,11 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             a.off = d_off;
             a.n_reads = n_reads;
             a.threshold = threshold;
-            a.S = t.d_S.p;
+            a.S_all = t.d_S.p;
+            a.group_stride = t.group_stride;
             a.ones_row = (uint32_t)(t.n_words * 64);
             a.rw = t.rw;
             a.rw_log2 = t.rw_log2;
-            a.n_leaves = (uint32_t)nl;
             a.n_cols = t.n_cols;
             a.guard_off = t.d_guard_off.p;
             a.guard_col = t.d_guard_col.p;
@@ -572,12 +659,24 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             a.allhit_flag = want_hits ? t.d_allhit.p : nullptr;
             a.stats = t.d_stats.p;
             int blocks = (int)std::min<uint64_t>((n_reads + 3) / 4, CLASSIFY_MAX_BLOCKS);  // (2048: 10.1 ms, 4096: 9.9 ms per step)
-            const bool counts_mode = !(threshold >= 1.0f);  // theta >= 1: need >= n for every read with k-mers
             if (counts_mode) {
                 HIP_TRY(t.d_long.ensure(n_reads + 1));
                 a.long_list = t.d_long.p;
                 a.n_long = reinterpret_cast<unsigned int *>(t.d_cursors.p + 4);
             }
+            // the frontier kernels, once per column group that holds leaves (a tree of up to 2048 columns has one group)
+            auto classify_groups = [&](bool defer) -> int {
+                const uint32_t leaf_groups = (uint32_t)((nl + 2047) / 2048);
+                for (uint32_t g = 0; g < leaf_groups; ++g) {
+                    a.S = t.d_S.p + (uint64_t)g * t.group_stride;
+                    a.col0 = g * 2048u;
+                    a.n_leaves = (uint32_t)std::min<size_t>(2048, nl - (size_t)g * 2048);
+                    a.first_group = g == 0;
+                    if (g && counts_mode) HIP_TRY(hipMemsetAsync(t.d_cursors.p + 4, 0, 8, st));  // the queue of long reads is per group
+                    pfq::launch_classify(a, defer, counts_mode, blocks, st);
+                }
+                return PFQ_OK;
+            };
             hipEvent_t *ev = nullptr;
             if (t.prof_used < t.prof_cap) {
                 ev = &t.prof_ev[PROF_EV * t.prof_used];
@@ -586,10 +685,6 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             }
             if (ev) HIP_TRY(hipEventRecord(ev[0], st));
             if (bucketed) {
-                // sub-buckets (keyed by the read index) keep every histogram counter cold when leaves are few
-                uint32_t sub_log2 = 0;
-                while (sub_log2 < 6 && (nl << sub_log2) < 1024) ++sub_log2;
-                const size_t nb = nl << sub_log2;
                 t.last_sub_log2 = sub_log2;
                 uint32_t *cnt = t.d_bucket.p, *off = cnt + nb, *cur = off + nb + 1;
                 a.pairs = t.d_pairs.p;
@@ -597,23 +692,12 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 a.pair_cursor = t.d_cursors.p + 1;
                 a.bucket_cnt = cnt;
                 a.sub_log2 = sub_log2;
-                // probe records: hash survivors once instead of once per slice (needs d < 2^30, <= 35 hashes, room)
-                uint4 *recs = nullptr;
-                if (recs_possible) {
-                    HIP_TRY(t.d_recs.ensure(total_bytes + 64));
-                    HIP_TRY(t.d_meta.ensure(t.d_pairs.n));
-                    recs = t.d_recs.p;
-                }
+                a.owner = with_guards ? t.d_owner.p : nullptr;
+                uint4 *recs = recs_possible ? t.d_recs.p : nullptr;
                 a.recs = recs;
                 a.rec_cap = recs ? t.d_recs.n : 0;
-                // thresholds < 1: every deferred pair owns ceil(n/64) words of k-mer miss bits that the slices OR into
                 uint32_t *cntw = nullptr, *offw = nullptr, *curw = nullptr;
                 if (counts_mode) {
-                    const uint64_t avg_len = n_reads ? total_bytes / n_reads : 0;
-                    const uint64_t miss_cap = std::min<uint64_t>(a.pair_cap * ((avg_len >> 6) + 2) + 4 * CLASSIFY_MAX_BLOCKS * 1024ull, 0xfffffff0ull);
-                    HIP_TRY(t.d_miss_words.ensure(miss_cap));
-                    HIP_TRY(t.d_miss_pos.ensure(t.d_pairs.n));
-                    HIP_TRY(t.d_bucket_w.ensure(3 * nb + 2));
                     cntw = t.d_bucket_w.p;
                     offw = cntw + nb;
                     curw = offw + nb + 1;
@@ -625,21 +709,23 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 }
                 uint32_t n_slices = 1;
                 uint64_t slice_target = SLICE_TARGET_BYTES;
-                if (const char *e = getenv("PFQ_SLICE_KB")) slice_target = strtoull(e, nullptr, 10) << 10;
+                if (kn.slice_kb > 0) slice_target = (uint64_t)kn.slice_kb << 10;
                 while (n_slices < 8 && (t.n_words * 8 + n_slices - 1) / n_slices > slice_target) n_slices <<= 1;
                 t.last_slices = n_slices;
                 HIP_TRY(hipMemsetAsync(cnt, 0, nb * 4, st));
                 HIP_TRY(hipMemsetAsync(t.d_fail.p, 0, t.d_fail.n * 4, st));
+                if (with_guards) HIP_TRY(hipMemsetAsync(t.d_gfail.p, 0, t.d_gfail.n * 4, st));
                 HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 128 * 4, st));
-                a.batch_tails = (recs && !counts_mode && !getenv("PFQ_NO_TAIL_BATCH")) ? 1u : 0u;
-                pfq::launch_classify(a, true, counts_mode, blocks, st);
+                a.batch_tails = (recs && !counts_mode && kn.no_tail_batch <= 0) ? 1u : 0u;
+                PFQ_TRY(classify_groups(true));
                 if (a.batch_tails) pfq::launch_tail_records(a, 2048, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
                 pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nb, st);
                 if (counts_mode) pfq::launch_bucket_scan(cntw, offw, curw, (uint32_t)nb, st);
                 pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, sub_log2, t.d_sorted.p,
                                            recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, offw, curw,
-                                           counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size, 1024, st);
+                                           counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size, a.owner,
+                                           with_guards ? t.d_owner_sorted.p : nullptr, 1024, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[2], st));
                 pfq::VerifyArgs v{};
                 v.hp = t.hp;
@@ -662,12 +748,12 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 // window of pairs in flight per slice = (blocks/8)*(8/n_slices)*4*chunk: about one leaf bucket
                 int vblocks = 512;
                 v.chunk = 1;
-                if (const char *e = getenv("PFQ_VERIFY_BLOCKS")) vblocks = std::max(8, atoi(e) & ~7);
-                if (const char *e = getenv("PFQ_VERIFY_CHUNK")) v.chunk = (uint32_t)std::max(1, atoi(e));
+                if (kn.verify_blocks >= 0) vblocks = std::max(8, (int)kn.verify_blocks & ~7);
+                if (kn.verify_chunk >= 0) v.chunk = (uint32_t)std::max(1, (int)kn.verify_chunk);
                 v.n_sub = 8;
-                if (const char *e = getenv("PFQ_VERIFY_SUB")) v.n_sub = (uint32_t)std::min(16, std::max(1, atoi(e)));
+                if (kn.verify_sub >= 0) v.n_sub = (uint32_t)std::min(16, std::max(1, (int)kn.verify_sub));
                 int vthreads = 512;
-                if (const char *e = getenv("PFQ_VERIFY_THREADS")) vthreads = std::min(1024, std::max(64, atoi(e) & ~63));
+                if (kn.verify_threads >= 0) vthreads = std::min(1024, std::max(64, (int)kn.verify_threads & ~63));
                 if (!recs) { vthreads = 256; vblocks = 1024; v.chunk = 4; }  // re-hash fallback kernel: 4-wave blocks
                 // LDS-tile certificates: every probe binned by (leaf chunk, 128 KiB filter tile), tiles tested out of LDS;
                 // k_verify_rec then only sees the pairs that could not be binned
@@ -677,29 +763,24 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 // 50 ms per step instead of 61 with none, 58 with 14 %, 65 with 36 %: break-even near a quarter); the share is the
                 // last call's (unknown: record kernel only).  Results do not depend on the choice.
                 bool tile_counts = t.dirty_frac < 0.2;
-                if (const char *e = getenv("PFQ_TILE_COUNTS")) tile_counts = atoi(e) != 0;
+                if (kn.tile_counts >= 0) tile_counts = kn.tile_counts != 0;
                 bool tile_mode = recs && (!counts_mode || tile_counts) && n_tiles < pfq::MAX_TILES;
-                if (const char *e = getenv("PFQ_TILE")) tile_mode = tile_mode && atoi(e) != 0;
-                uint64_t tile_budget = 64ull << 30;
-                if (const char *e = getenv("PFQ_TILE_GB")) tile_budget = strtoull(e, nullptr, 10) << 30;
+                if (kn.tile >= 0) tile_mode = tile_mode && kn.tile != 0;
+                if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = 0; }
+                uint64_t tile_budget = std::min<uint64_t>(64ull << 30, (uint64_t)((double)(mem_free + t.d_entries.bytes()) * 0.8));
+                if (kn.tile_gb >= 0) tile_budget = (uint64_t)kn.tile_gb << 30;
                 t.last_tile_mode = 0;
                 if (tile_mode) {
                     // every read may survive with one candidate: (bases - (k-1) per read) * hashes * 1.125 + slack per bucket
-                    const uint64_t max_chunks = nl + (a.pair_cap >> pfq::CHUNK_PAIRS_LOG2) + 2;
+                    const uint64_t max_chunks = nc + (a.pair_cap >> pfq::CHUNK_PAIRS_LOG2) + 2;
                     uint64_t want = (uint64_t)((double)total_bytes * t.num_hashes * 1.13 * std::max(1.0, t.pairs_per_read)) +
                                     max_chunks * n_tiles * 544ull;
                     if (want * 4 > tile_budget) want = tile_budget / 4;
-                    if (const char *e = getenv("PFQ_TILE_ENTRIES")) want = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // tests: force passes
-                    hipError_t e1 = t.d_entries.ensure(want);
-                    if (e1 != hipSuccess) {
-                        (void)hipGetLastError();
+                    if (kn.tile_entries >= 0) want = std::max<uint64_t>(1, (uint64_t)kn.tile_entries);  // tests: force passes
+                    if (!(soft_ensure(t.d_entries, want) && soft_ensure(t.d_pair_chunk, t.d_pairs.n) && soft_ensure(t.d_flag_list, t.d_pairs.n) &&
+                          soft_ensure(t.d_leaf_chunk0, nc + 1) && soft_ensure(t.d_chunks, max_chunks) && soft_ensure(t.d_gfill, max_chunks * n_tiles))) {
                         tile_mode = false;  // not enough HBM for the probe buckets: stay with the record kernel
                     } else {
-                        HIP_TRY(t.d_pair_chunk.ensure(t.d_pairs.n));
-                        HIP_TRY(t.d_flag_list.ensure(t.d_pairs.n));
-                        HIP_TRY(t.d_leaf_chunk0.ensure(nl + 1));
-                        HIP_TRY(t.d_chunks.ensure(max_chunks));
-                        HIP_TRY(t.d_gfill.ensure(max_chunks * n_tiles));
                         HIP_TRY(hipMemsetAsync(t.d_gfill.p, 0, max_chunks * n_tiles * 4, st));
                         pfq::TileArgs ta{};
                         ta.hp = t.hp;
@@ -709,7 +790,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         ta.meta = t.d_meta.p;
                         ta.bucket_off = off;
                         ta.sub_log2 = sub_log2;
-                        ta.n_leaves = (uint32_t)nl;
+                        ta.n_leaves = (uint32_t)nc;
                         ta.n_tiles = n_tiles;
                         ta.chunks = t.d_chunks.p;
                         ta.max_chunks = (uint32_t)max_chunks;
@@ -727,8 +808,9 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         ta.fail = t.d_fail.p;
                         ta.n_pairs_ptr = off + nb;
                         int bin_blocks = 512, test_blocks = 512;
-                        if (const char *e = getenv("PFQ_BIN_BLOCKS")) bin_blocks = std::max(1, atoi(e));
-                        if (const char *e = getenv("PFQ_TEST_BLOCKS")) test_blocks = std::max(1, atoi(e));
+                        if (kn.bin_blocks >= 0) bin_blocks = std::max(1, (int)kn.bin_blocks);
+                        if (kn.test_blocks >= 0) test_blocks = std::max(1, (int)kn.test_blocks);
+                        ta.bin_shape = kn.bin_narrow > 0 ? 1u : (kn.bin_wide > 0 ? 2u : 0u);
                         pfq::launch_tile_plan(ta, st);
                         // The probe buckets of all pairs may exceed the buffer (reads that pass many leaves): the plan
                         // spreads the chunks over passes that reuse it.  Their number is known on the device only; as
@@ -783,18 +865,28 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 f.miss_words = v.miss_words;
                 f.miss_pos = v.miss_pos;
                 f.threshold = threshold;
-                f.n_leaves = (uint32_t)nl;
                 f.counts = t.d_counts.p;
                 f.hit_pairs = a.hit_pairs;
                 f.hit_cap = hit_cap;
                 f.hit_cursor = t.d_cursors.p;
                 f.stats = t.d_stats.p;
                 f.n_dirty = t.d_cursors.p + 6;
+                f.owner_sorted = with_guards ? t.d_owner_sorted.p : nullptr;
+                f.gfail = with_guards ? t.d_gfail.p : nullptr;
                 t.hint_counts = counts_mode;
+                if (with_guards) {  // the guard columns first: a guard that does not pass marks its leaf pair
+                    f.c0 = (uint32_t)nl;
+                    f.c1 = (uint32_t)nc;
+                    f.guards = 1;
+                    pfq::launch_finalize(f, st);
+                }
+                f.c0 = 0;
+                f.c1 = (uint32_t)nl;
+                f.guards = 0;
                 pfq::launch_finalize(f, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[6], st));
             } else {
-                pfq::launch_classify(a, false, counts_mode, blocks, st);
+                PFQ_TRY(classify_groups(false));
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
             }
             HIP_TRY(hipGetLastError());
@@ -803,7 +895,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             HIP_TRY(hipMemcpyAsync(t.h_pair_cursor, t.d_cursors.p + 1, 16, hipMemcpyDeviceToHost, st));  // pair cursor, bucket cursor
             HIP_TRY(hipMemcpyAsync(t.h_pair_cursor + 2, t.d_cursors.p + 6, 8, hipMemcpyDeviceToHost, st));  // pairs with a k-mer missing
             if (n_reads && nl)  // ... of how many sorted pairs (the pair cursor also counts partly used reservations)
-                HIP_TRY(hipMemcpyAsync(t.h_pair_cursor + 3, t.d_bucket.p + 2 * (nl << t.last_sub_log2), 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(t.h_pair_cursor + 3, t.d_bucket.p + 2 * (nc << t.last_sub_log2), 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipEventRecord(t.hint_ev, st));
             t.hint_reads = n_reads;
         }
@@ -845,11 +937,67 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     return fail(PFQ_ERR_DEVICE, "hit buffer overflow persisted");
 }
 
+// Reduce a whole tree to subtree shard `index` of the depth-`depth` frontier (pfq_tree_open_subtree): the shard's node,
+// everything below it and the chain of its ancestors, each reduced to the child on the path.  `reachable` marks the nodes
+// that stay; `chain` lists the ancestors, root first.  Needs parent / depth of every node (relink).
+int apply_shard(pfq_tree &t, uint64_t depth, uint64_t index, std::vector<uint8_t> &reachable, std::vector<int32_t> &chain) {
+    if (t.root < 0) return fail(PFQ_ERR_STATE, "subtree shard of an empty tree");
+    // frontier at depth `depth`, left to right: nodes at that depth and leaves above it
+    std::vector<int32_t> frontier, st{t.root};
+    while (!st.empty()) {
+        int32_t v = st.back();
+        st.pop_back();
+        const Node &nd = t.nodes[v];
+        if (nd.depth == depth || nd.is_leaf()) { frontier.push_back(v); continue; }
+        if (nd.right >= 0) st.push_back(nd.right);
+        if (nd.left >= 0) st.push_back(nd.left);
+    }
+    if (index >= frontier.size())
+        return fail(PFQ_ERR_ARG, "subtree index " + std::to_string(index) + " out of range: the depth-" +
+                                     std::to_string(depth) + " frontier has " + std::to_string(frontier.size()) + " nodes");
+    const int32_t target = frontier[index];
+    // leaves before the shard in the whole tree's order
+    auto count_leaves = [&](int32_t root) {
+        uint64_t n = 0;
+        std::vector<int32_t> s2{root};
+        while (!s2.empty()) {
+            int32_t v = s2.back();
+            s2.pop_back();
+            const Node &nd = t.nodes[v];
+            if (nd.is_leaf()) ++n;
+            if (nd.left >= 0) s2.push_back(nd.left);
+            if (nd.right >= 0) s2.push_back(nd.right);
+        }
+        return n;
+    };
+    t.shard_first_leaf = 0;
+    for (uint64_t i = 0; i < index; ++i) t.shard_first_leaf += count_leaves(frontier[i]);
+    // reduce every ancestor to the child on the path
+    chain.clear();
+    for (int32_t c = target, v = t.nodes[target].parent; v >= 0; c = v, v = t.nodes[v].parent) {
+        if (t.nodes[v].left != c) t.nodes[v].left = -1;
+        if (t.nodes[v].right != c) t.nodes[v].right = -1;
+        chain.insert(chain.begin(), v);
+    }
+    reachable.assign(t.nodes.size(), 0);
+    std::vector<int32_t> s3{t.root};
+    while (!s3.empty()) {
+        int32_t v = s3.back();
+        s3.pop_back();
+        reachable[v] = 1;
+        if (t.nodes[v].left >= 0) s3.push_back(t.nodes[v].left);
+        if (t.nodes[v].right >= 0) s3.push_back(t.nodes[v].right);
+    }
+    t.is_shard = true;
+    return PFQ_OK;
+}
+
 // Balanced synthetic tree topology; same numbering as oracle/pfq_oracle.py:build_balanced_tree.
 int32_t build_balanced_rec(pfq_tree &t, const char *const *tax_ids, uint64_t lo, uint64_t hi, int32_t parent,
-                           uint32_t depth, uint64_t &internal_counter) {
+                           uint32_t depth, uint64_t &internal_counter, std::vector<std::pair<uint64_t, uint64_t>> &range) {
     int32_t v = (int32_t)t.nodes.size();
     t.nodes.emplace_back();
+    range.emplace_back(lo, hi);  // genomes below node v
     t.nodes[v].parent = parent;
     t.nodes[v].depth = depth;
     t.nodes[v].filter = (uint32_t)v;
@@ -862,16 +1010,19 @@ int32_t build_balanced_rec(pfq_tree &t, const char *const *tax_ids, uint64_t lo,
     t.nodes[v].tax_id = "Internal_Node_" + std::to_string(internal_counter++);
     t.nodes[v].bf_path = t.nodes[v].tax_id + ".bf";
     uint64_t mid = lo + (hi - lo + 1) / 2;
-    int32_t l = build_balanced_rec(t, tax_ids, lo, mid, v, depth + 1, internal_counter);
-    int32_t r = build_balanced_rec(t, tax_ids, mid, hi, v, depth + 1, internal_counter);
+    int32_t l = build_balanced_rec(t, tax_ids, lo, mid, v, depth + 1, internal_counter, range);
+    int32_t r = build_balanced_rec(t, tax_ids, mid, hi, v, depth + 1, internal_counter, range);
     t.nodes[v].left = l;
     t.nodes[v].right = r;
     return v;
 }
 
+// shard: only subtree shard `shard_index` of the depth-`shard_depth` frontier is materialised (its subtree bottom-up from
+// its own genomes; every ancestor on the chain = the union of ALL genomes below it in the whole tree, inserted directly).
 int build_balanced_common(const uint8_t *d_genomes, const uint64_t *d_goff, uint64_t n_genomes, const char *const *tax_ids,
                           uint64_t kmer_size, uint64_t nbits, uint32_t num_hashes, uint64_t seed1, uint64_t seed2,
-                          float fpr, uint32_t largest, int device, pfq_tree **out) {
+                          float fpr, uint32_t largest, int device, bool shard, uint64_t shard_depth, uint64_t shard_index,
+                          pfq_tree **out) {
     std::unique_ptr<pfq_tree> t(new pfq_tree());
     t->device = device;
     t->kmer_size = kmer_size;
@@ -882,34 +1033,69 @@ int build_balanced_common(const uint8_t *d_genomes, const uint64_t *d_goff, uint
     t->false_pos_rate = fpr;
     t->largest_expected_genome = largest;
     PFQ_TRY(setup_hash_params(*t));
-    if (n_genomes > 65535) return fail(PFQ_ERR_UNSUPPORTED, "more than 65535 genomes in one balanced build");
+    if (n_genomes > (1u << 24)) return fail(PFQ_ERR_UNSUPPORTED, "more than 2^24 genomes in one balanced build");
+    std::vector<std::pair<uint64_t, uint64_t>> range;
     if (n_genomes) {
         uint64_t counter = 0;
-        t->root = build_balanced_rec(*t, tax_ids, 0, n_genomes, -1, 0, counter);
+        t->root = build_balanced_rec(*t, tax_ids, 0, n_genomes, -1, 0, counter, range);
     }
-    const size_t nn = t->nodes.size();
-    for (auto &nd : t->nodes) t->filter_paths.push_back(nd.bf_path);
-    if (nn) {
-        HIP_TRY(t->d_bits.ensure(nn * t->n_words));
-        t->n_rows = t->row_capacity = nn;
-        HIP_TRY(hipMemset(t->d_bits.p, 0, nn * t->n_words * 8));
-        // leaves: genome order == left-to-right leaf order
-        std::vector<int32_t> lv = leaves_dfs(*t);
-        std::vector<uint32_t> leaf_row(lv.size());
-        for (size_t i = 0; i < lv.size(); ++i) leaf_row[i] = t->nodes[lv[i]].filter;
+    t->tree_leaves = n_genomes;
+    std::vector<uint8_t> reachable(t->nodes.size(), 1);
+    std::vector<int32_t> chain;
+    if (shard) PFQ_TRY(apply_shard(*t, shard_depth, shard_index, reachable, chain));
+    std::vector<uint8_t> on_chain(t->nodes.size(), 0);
+    for (int32_t v : chain) on_chain[v] = 1;
+    // filter rows: one per node that stays (a whole tree: row == node index)
+    for (size_t v = 0; v < t->nodes.size(); ++v) {
+        if (!reachable[v]) continue;
+        t->nodes[v].filter = (uint32_t)t->filter_paths.size();
+        t->filter_paths.push_back(t->nodes[v].bf_path);
+    }
+    const size_t nn = t->nodes.size(), nrows = t->filter_paths.size();
+    if (nrows) {
+        if (t->d_bits.ensure(nrows * t->n_words) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(PFQ_ERR_DEVICE, "not enough device memory for " + std::to_string(nrows) + " filters of " +
+                                            std::to_string(t->n_words * 8) + " bytes");
+        }
+        t->n_rows = t->row_capacity = nrows;
+        HIP_TRY(hipMemset(t->d_bits.p, 0, nrows * t->n_words * 8));
+        // genome -> filter rows it is inserted into: its leaf (when the leaf stays) and every ancestor on the shard's chain
+        // (k_insert takes one row per genome and launch; the chain is a handful of nodes)
         DevBuf<uint32_t> d_leaf_row, d_triples;
-        HIP_TRY(d_leaf_row.ensure(leaf_row.size()));
-        HIP_TRY(hipMemcpy(d_leaf_row.p, leaf_row.data(), leaf_row.size() * 4, hipMemcpyHostToDevice));
-        pfq::launch_insert(t->hp, d_genomes, d_goff, (uint32_t)n_genomes, d_leaf_row.p, t->d_bits.p, t->n_words, nullptr);
-        HIP_TRY(hipGetLastError());
-        // internal nodes bottom-up, one launch per depth
+        HIP_TRY(d_leaf_row.ensure(n_genomes + 1));
+        std::vector<uint32_t> leaf_row(n_genomes, 0xffffffffu);
+        for (size_t v = 0; v < nn; ++v)
+            if (reachable[v] && range[v].second - range[v].first == 1 && t->nodes[v].is_leaf() && !on_chain[v])
+                leaf_row[range[v].first] = t->nodes[v].filter;
+        auto insert_range = [&](uint64_t lo, uint64_t hi) -> int {  // genomes [lo, hi) with rows leaf_row[lo..hi)
+            // runs of genomes that have a row; blockIdx.y is limited to 65535 genomes per launch
+            for (uint64_t g = lo; g < hi;) {
+                if (leaf_row[g] == 0xffffffffu) { ++g; continue; }
+                uint64_t e = g;
+                while (e < hi && e - g < 32768 && leaf_row[e] != 0xffffffffu) ++e;
+                HIP_TRY(hipMemcpy(d_leaf_row.p, leaf_row.data() + g, (e - g) * 4, hipMemcpyHostToDevice));
+                pfq::launch_insert(t->hp, d_genomes, d_goff + g, (uint32_t)(e - g), d_leaf_row.p, t->d_bits.p, t->n_words, nullptr);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipDeviceSynchronize());
+                g = e;
+            }
+            return PFQ_OK;
+        };
+        PFQ_TRY(insert_range(0, n_genomes));
+        for (int32_t v : chain) {  // ancestors of the shard: every genome below them, straight into their row
+            std::fill(leaf_row.begin(), leaf_row.end(), 0xffffffffu);
+            for (uint64_t g = range[v].first; g < range[v].second; ++g) leaf_row[g] = t->nodes[v].filter;
+            PFQ_TRY(insert_range(range[v].first, range[v].second));
+        }
+        // internal nodes of the (sub)tree bottom-up, one launch per depth
         uint32_t max_depth = 0;
         for (auto &nd : t->nodes) max_depth = std::max(max_depth, nd.depth);
         for (int d = (int)max_depth; d >= 0; --d) {
             std::vector<uint32_t> triples;
             for (size_t v = 0; v < nn; ++v) {
                 const Node &nd = t->nodes[v];
-                if ((int)nd.depth != d || nd.is_leaf()) continue;
+                if ((int)nd.depth != d || nd.is_leaf() || !reachable[v] || on_chain[v]) continue;
                 triples.push_back(nd.filter);
                 triples.push_back(t->nodes[nd.left].filter);
                 triples.push_back(t->nodes[nd.right].filter);
@@ -994,53 +1180,8 @@ static int open_impl(const char *db_dir, int device, bool shard, uint64_t shard_
     if (!c.ok || c.p != c.n) return fail(PFQ_ERR_FORMAT, "tree.bin: truncated or trailing bytes");
     t->tree_leaves = leaves_dfs(*t).size();
     std::vector<uint8_t> reachable(t->nodes.size(), 1);
-    if (shard) {
-        if (t->root < 0) return fail(PFQ_ERR_STATE, "subtree shard of an empty tree");
-        // frontier at depth `shard_depth`, left to right: nodes at that depth and leaves above it
-        std::vector<int32_t> frontier, st{t->root};
-        while (!st.empty()) {
-            int32_t v = st.back();
-            st.pop_back();
-            const Node &nd = t->nodes[v];
-            if (nd.depth == shard_depth || nd.is_leaf()) { frontier.push_back(v); continue; }
-            if (nd.right >= 0) st.push_back(nd.right);
-            if (nd.left >= 0) st.push_back(nd.left);
-        }
-        if (shard_index >= frontier.size())
-            return fail(PFQ_ERR_ARG, "subtree index " + std::to_string(shard_index) + " out of range: the depth-" +
-                                         std::to_string(shard_depth) + " frontier has " + std::to_string(frontier.size()) + " nodes");
-        const int32_t target = frontier[shard_index];
-        // leaves before the shard in the whole tree's order
-        auto count_leaves = [&](int32_t root) {
-            uint64_t n = 0;
-            std::vector<int32_t> s2{root};
-            while (!s2.empty()) {
-                int32_t v = s2.back();
-                s2.pop_back();
-                const Node &nd = t->nodes[v];
-                if (nd.is_leaf()) ++n;
-                if (nd.left >= 0) s2.push_back(nd.left);
-                if (nd.right >= 0) s2.push_back(nd.right);
-            }
-            return n;
-        };
-        for (uint64_t i = 0; i < shard_index; ++i) t->shard_first_leaf += count_leaves(frontier[i]);
-        // reduce every ancestor to the child on the path
-        for (int32_t c = target, v = t->nodes[target].parent; v >= 0; c = v, v = t->nodes[v].parent) {
-            if (t->nodes[v].left != c) t->nodes[v].left = -1;
-            if (t->nodes[v].right != c) t->nodes[v].right = -1;
-        }
-        std::fill(reachable.begin(), reachable.end(), 0);
-        std::vector<int32_t> s3{t->root};
-        while (!s3.empty()) {
-            int32_t v = s3.back();
-            s3.pop_back();
-            reachable[v] = 1;
-            if (t->nodes[v].left >= 0) s3.push_back(t->nodes[v].left);
-            if (t->nodes[v].right >= 0) s3.push_back(t->nodes[v].right);
-        }
-        t->is_shard = true;
-    }
+    std::vector<int32_t> chain;
+    if (shard) PFQ_TRY(apply_shard(*t, shard_depth, shard_index, reachable, chain));
     // filters keyed by relative path, exactly like the LRU cache key (cache.rs:56-62)
     std::map<std::string, uint32_t> row_of;
     for (size_t vi = 0; vi < t->nodes.size(); ++vi) {
@@ -1189,6 +1330,14 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
     pfq_tree &t = *tree;
     if (t.is_shard) return fail(PFQ_ERR_STATE, "a subtree shard cannot be extended");
     if (t.n_words == 0) return fail(PFQ_ERR_STATE, "tree has no filter geometry");
+    // One .bf per node here.  (The reference keys filters by file name: a second node called <tax_id> gets a fresh empty
+    // filter under the first one's key, bloom_tree.rs:294 / cache.rs:83-87, and the two then share one file on disk —
+    // SURVEY H4.  Such databases can be OPENED; building one is refused.)
+    auto path_taken = [&](const std::string &pth) { return std::find(t.filter_paths.begin(), t.filter_paths.end(), pth) != t.filter_paths.end(); };
+    if (path_taken(std::string(tax_id) + ".bf"))
+        return fail(PFQ_ERR_ARG, std::string("a node named ") + tax_id + " exists already: two nodes would share " + tax_id + ".bf");
+    if (internal_name && (path_taken(std::string(internal_name) + ".bf") || !strcmp(internal_name, tax_id)))
+        return fail(PFQ_ERR_ARG, std::string("a node named ") + internal_name + " exists already: two nodes would share " + internal_name + ".bf");
     PFQ_TRY(sync_counts_to_nodes(t));
     t.layout_valid = false;
     PFQ_TRY(reserve_rows(t, t.n_rows + 2));
@@ -1283,7 +1432,7 @@ int pfq_tree_build_balanced(const uint8_t *genomes, const uint64_t *offsets, uin
     if (total) HIP_TRY(hipMemcpy(d_g.p, genomes, total, hipMemcpyHostToDevice));
     if (n_genomes) HIP_TRY(hipMemcpy(d_o.p, offsets, (n_genomes + 1) * 8, hipMemcpyHostToDevice));
     return build_balanced_common(d_g.p, d_o.p, n_genomes, tax_ids, kmer_size, nbits, num_hashes, seed1, seed2,
-                                 false_pos_rate, largest_expected_genome, device, out);
+                                 false_pos_rate, largest_expected_genome, device, false, 0, 0, out);
 }
 
 int pfq_tree_build_balanced_device(const uint8_t *d_genomes, uint64_t genome_len, uint64_t n_genomes,
@@ -1299,13 +1448,31 @@ int pfq_tree_build_balanced_device(const uint8_t *d_genomes, uint64_t genome_len
     HIP_TRY(d_o.ensure(n_genomes + 1));
     HIP_TRY(hipMemcpy(d_o.p, off.data(), off.size() * 8, hipMemcpyHostToDevice));
     return build_balanced_common(d_genomes, d_o.p, n_genomes, tax_ids, kmer_size, nbits, num_hashes, seed1, seed2,
-                                 false_pos_rate, largest_expected_genome, device, out);
+                                 false_pos_rate, largest_expected_genome, device, false, 0, 0, out);
+}
+
+int pfq_tree_build_balanced_subtree_device(const uint8_t *d_genomes, uint64_t genome_len, uint64_t n_genomes,
+                                           const char *const *tax_ids, uint64_t kmer_size, uint64_t nbits, uint32_t num_hashes,
+                                           uint64_t seed1, uint64_t seed2, float false_pos_rate, uint32_t largest_expected_genome,
+                                           uint64_t depth, uint64_t index, int device, pfq_tree **out) {
+    if (!out || (n_genomes && (!d_genomes || !tax_ids))) return fail(PFQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    PFQ_TRY(use_device(device));
+    std::vector<uint64_t> off(n_genomes + 1);
+    for (uint64_t i = 0; i <= n_genomes; ++i) off[i] = i * genome_len;
+    DevBuf<uint64_t> d_o;
+    HIP_TRY(d_o.ensure(n_genomes + 1));
+    HIP_TRY(hipMemcpy(d_o.p, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    return build_balanced_common(d_genomes, d_o.p, n_genomes, tax_ids, kmer_size, nbits, num_hashes, seed1, seed2,
+                                 false_pos_rate, largest_expected_genome, device, true, depth, index, out);
 }
 
 int pfq_tree_save(const pfq_tree *tree, const char *db_dir) {
     if (!tree || !db_dir) return fail(PFQ_ERR_ARG, "null argument");
     PFQ_TRY(use_device(tree->device));
     PFQ_TRY(finish_topology(*const_cast<pfq_tree *>(tree)));
+    // BloomTree::save writes the live mapped_reads (bloom_tree.rs:339-355): fold the device counters back first
+    PFQ_TRY(sync_counts_to_nodes(*const_cast<pfq_tree *>(tree)));
     const pfq_tree &t = *tree;
     if (t.is_shard) return fail(PFQ_ERR_STATE, "a subtree shard is not a whole database and cannot be saved");
     std::string dir(db_dir);
@@ -1490,6 +1657,116 @@ int pfq_leaf_counts_import(pfq_tree *tree, const uint64_t *d_src, void *stream) 
         HIP_TRY(hipMemcpyAsync(tree->d_counts.p, d_src, tree->leaves.size() * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PFQ_OK;
 }
+// ---- several replicas behind one process: one RCCL all-reduce of the per-leaf counters -------------------------------
+extern "C++" {
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+Rccl &rccl() {  // loaded once per process; RCCL is a run-time dependency of multi-GPU runs only
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!r.handle) r.handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!r.handle) {
+            r.error = std::string("cannot load librccl: ") + dlerror();
+            return;
+        }
+        auto sym = [&](const char *name) {
+            void *p = dlsym(r.handle, name);
+            if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + name;
+            return p;
+        };
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    });
+    return r;
+}
+thread_local uint32_t g_last_ranks = 0;
+}  // namespace
+}  // extern "C++"
+
+uint32_t pfq_last_allreduce_ranks(void) { return g_last_ranks; }
+
+int pfq_trees_allreduce_counts(pfq_tree *const *trees, uint32_t n_trees) {
+    g_last_ranks = 0;
+    if (!trees || n_trees == 0) return fail(PFQ_ERR_ARG, "null argument");
+    for (uint32_t i = 0; i < n_trees; ++i)
+        if (!trees[i]) return fail(PFQ_ERR_ARG, "null tree");
+    // every replica: same leaf set, queued work finished
+    std::map<int, std::vector<pfq_tree *>> by_dev;  // device -> replicas on it, the first one leads
+    for (uint32_t i = 0; i < n_trees; ++i) {
+        pfq_tree &t = *trees[i];
+        for (uint32_t j = 0; j < i; ++j)
+            if (trees[j] == trees[i]) return fail(PFQ_ERR_ARG, "the same tree listed twice");
+        PFQ_TRY(use_device(t.device));
+        PFQ_TRY(build_layout(t));
+        HIP_TRY(hipDeviceSynchronize());
+        if (t.leaves.size() != trees[0]->leaves.size())
+            return fail(PFQ_ERR_ARG, "the trees are not replicas of one database: " + std::to_string(t.leaves.size()) + " vs " +
+                                         std::to_string(trees[0]->leaves.size()) + " leaves");
+        for (size_t l = 0; l < t.leaves.size(); ++l)
+            if (t.nodes[t.leaves[l]].tax_id != trees[0]->nodes[trees[0]->leaves[l]].tax_id)
+                return fail(PFQ_ERR_ARG, "the trees are not replicas of one database: leaf " + std::to_string(l) + " differs");
+        by_dev[t.device].push_back(&t);
+    }
+    const uint32_t nl = (uint32_t)trees[0]->leaves.size();
+    if (n_trees == 1 || nl == 0) return PFQ_OK;
+    // (1) replicas that share a device: added into the device's first replica
+    for (auto &kv : by_dev) {
+        HIP_TRY(hipSetDevice(kv.first));
+        for (size_t r = 1; r < kv.second.size(); ++r)
+            pfq::launch_add_counts(kv.second[0]->d_counts.p, kv.second[r]->d_counts.p, nl, nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    // (2) one all-reduce (sum, u64[n_leaves]) over RCCL across the devices, in place in each device's first replica
+    Rccl &r = rccl();
+    if (!r.error.empty()) return fail(PFQ_ERR_DEVICE, r.error);
+    std::vector<int> devs;
+    for (auto &kv : by_dev) devs.push_back(kv.first);
+    std::vector<ncclComm_t> comms(devs.size());
+    ncclResult_t rc = r.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+    if (rc != ncclSuccess) return fail(PFQ_ERR_DEVICE, std::string("ncclCommInitAll: ") + r.GetErrorString(rc));
+    rc = r.GroupStart();
+    for (size_t i = 0; i < devs.size() && rc == ncclSuccess; ++i) {
+        (void)hipSetDevice(devs[i]);
+        unsigned long long *buf = by_dev[devs[i]][0]->d_counts.p;
+        rc = r.AllReduce(buf, buf, nl, ncclUint64, ncclSum, comms[i], nullptr);
+    }
+    const ncclResult_t rc_end = r.GroupEnd();
+    if (rc == ncclSuccess) rc = rc_end;
+    hipError_t he = hipSuccess;
+    for (size_t i = 0; i < devs.size(); ++i) {
+        (void)hipSetDevice(devs[i]);
+        const hipError_t e = hipDeviceSynchronize();
+        if (he == hipSuccess) he = e;
+    }
+    for (auto c : comms) (void)r.CommDestroy(c);
+    if (rc != ncclSuccess) return fail(PFQ_ERR_DEVICE, std::string("ncclAllReduce: ") + r.GetErrorString(rc));
+    if (he != hipSuccess) return fail(PFQ_ERR_DEVICE, std::string("all-reduce of the leaf counters: ") + hipGetErrorString(he));
+    g_last_ranks = (uint32_t)devs.size();
+    // (3) the totals go back to the other replicas of each device
+    for (auto &kv : by_dev) {
+        HIP_TRY(hipSetDevice(kv.first));
+        for (size_t q = 1; q < kv.second.size(); ++q)
+            HIP_TRY(hipMemcpy(kv.second[q]->d_counts.p, kv.second[0]->d_counts.p, (size_t)nl * 8, hipMemcpyDeviceToDevice));
+    }
+    return PFQ_OK;
+}
+
 int pfq_leaf_counts_reset(pfq_tree *tree) {
     if (!tree) return fail(PFQ_ERR_ARG, "null argument");
     PFQ_TRY(use_device(tree->device));
@@ -1570,6 +1847,11 @@ int pfq_profile_end(pfq_tree *tree, pfq_profile *out) {
     }
     out->calls = t.prof_used;
     t.prof_cap = t.prof_used = 0;
+    return PFQ_OK;
+}
+int pfq_set_option(pfq_tree *tree, const char *name, const char *value) {
+    if (!tree || !name) return fail(PFQ_ERR_ARG, "null argument");
+    if (!set_knob(tree->knobs, name, value)) return fail(PFQ_ERR_ARG, std::string("unknown option ") + name);
     return PFQ_OK;
 }
 int pfq_set_path(pfq_tree *tree, int path) {

@@ -3,9 +3,11 @@
 //
 //   bits   u64[n_filters][n_words]   node-major filters in the reference's own bit order (BitVec<usize,Lsb0>,
 //                                    bloom_filter.rs:86): bit idx = word idx>>6, mask 1<<(idx&63).
-//   S      u32[n_words*64 + 1][rw]   "sliced" matrix (last row: all ones, the target of predicated-off gathers): row = bit index, column = leaf (left-to-right DFS order)
-//                                    followed by guard columns (ancestors whose ⊇ check failed).  One 128-B line
-//                                    answers the same probe for 1024 leaves.
+//   S      u32[groups][n_words*64 + 1][rw]   "sliced" matrix (last row of a group: all ones, the target of predicated-off
+//                                    gathers): row = bit index, column = leaf (left-to-right DFS order) followed by guard
+//                                    columns (ancestors whose ⊇ check failed).  One 128-B line answers the same probe for
+//                                    1024 leaves.  Trees of more than 2048 columns are cut into column groups of 2048
+//                                    (rw = 64 each); the frontier kernels run once per group.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,12 +25,17 @@ struct QueryArgs {
     uint64_t n_reads;
     float threshold;
     // sliced matrix
-    const uint32_t *S;
+    const uint32_t *S;           // the column group this launch screens
+    const uint32_t *S_all;       // group 0 (certificates of arbitrary columns: guards may live in another group)
+    uint64_t group_stride;       // dwords between the matrices of consecutive groups
+    uint32_t col0;               // first column of this launch's group (columns are global everywhere else)
+    uint32_t first_group;        // 1: this launch accounts for the per-read statistics (read bytes, all-hit reads)
     uint32_t ones_row;           // index of the all-ones row stored behind the last bit row of S
     uint32_t rw, rw_log2;        // row words (power of two <= 64)
-    uint32_t n_leaves, n_cols;   // leaf columns, leaf+guard columns
-    const uint32_t *guard_off;   // [n_leaves+1] CSR into guard_col (may be all zeros)
-    const uint32_t *guard_col;
+    uint32_t n_leaves, n_cols;   // leaf columns of this group; leaf+guard columns of the tree
+    const uint32_t *guard_off;   // [total leaves + 1] CSR into guard_col (may be all zeros), indexed by global leaf column
+    const uint32_t *guard_col;   // global columns
+    uint32_t *owner;             // trees with guard columns: per pair slot, the slot of the leaf pair it belongs to (else nullptr)
     // results
     unsigned long long *counts;  // [n_leaves]  mapped_reads, accumulating (query.rs:143)
     uint2 *hit_pairs;            // (read, leaf) or nullptr
@@ -97,7 +104,10 @@ struct FinalizeArgs {
     const unsigned long long *miss_words;  // thresholds < 1 (see VerifyArgs); nullptr at threshold 1
     const uint32_t *miss_pos;
     float threshold;
-    uint32_t n_leaves;
+    uint32_t c0, c1;             // buckets (columns) of this launch: the guard columns first, then the leaves
+    uint32_t guards;             // 1: guard columns — a pair that does not pass marks its leaf pair in gfail; no counts, no hits
+    const uint32_t *owner_sorted;  // trees with guard columns: per sorted pair, the slot of its leaf pair (else nullptr)
+    uint32_t *gfail;             // per pair slot: a guard of this leaf pair did not pass
     unsigned long long *counts;
     uint2 *hit_pairs;
     uint64_t hit_cap;
@@ -130,7 +140,8 @@ struct TileArgs {
     const uint4 *recs;
     const uint4 *meta;           // per sorted pair (read offset lo, hi, length, row)
     const uint32_t *bucket_off;  // [(n_leaves << sub_log2) + 1]
-    uint32_t sub_log2, n_leaves, n_tiles;
+    uint32_t sub_log2, n_leaves, n_tiles;   // n_leaves: buckets = leaf + guard columns
+    uint32_t bin_shape;          // 0 auto, 1 force the 8 x 128 build of k_tile_bin, 2 force 16 x 256
     ChunkDesc *chunks;           // [max_chunks]
     uint32_t max_chunks;
     uint32_t *leaf_chunk0;       // [n_leaves + 1] first chunk of each leaf (chunks of a leaf are contiguous)
@@ -158,7 +169,8 @@ void launch_bucket_scan(const uint32_t *bucket_cnt, uint32_t *bucket_off, uint32
 void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
                            const uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t sub_log2, uint2 *sorted, uint4 *meta,
                            const uint64_t *read_off, const uint32_t *col_row, const uint32_t *words_off, uint32_t *words_cur,
-                           uint32_t *miss_pos, uint32_t kmer_size, int blocks, hipStream_t st);
+                           uint32_t *miss_pos, uint32_t kmer_size, const uint32_t *owner, uint32_t *owner_sorted, int blocks,
+                           hipStream_t st);
 void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st);
 // list = the sorted pairs with a non-zero fail word, in order within runs; *n_out += their number (thresholds < 1 after tile passes)
 void launch_collect_open(const uint32_t *fail, const uint32_t *n_pairs_ptr, uint32_t *list, uint32_t cap, unsigned int *n_out, hipStream_t st);
@@ -177,7 +189,9 @@ void launch_insert_step(uint64_t *bits, uint64_t n_words, uint32_t cur_row, uint
 void launch_superset(const uint64_t *bits, uint64_t n_words, const uint32_t *d_edges /*(parent,child)*/, uint32_t n_edges,
                      uint32_t *d_fail, hipStream_t st);
 void launch_transpose(const uint64_t *bits, uint64_t n_words, const uint32_t *d_col_row, uint32_t n_cols, uint32_t *S,
-                      uint32_t rw, hipStream_t st);
+                      uint32_t rw, uint64_t group_stride, hipStream_t st);
+// dst[i] += src[i] (u64 counters; replicas of one tree on the same device, pfq_trees_allreduce_counts)
+void launch_add_counts(unsigned long long *dst, const unsigned long long *src, uint32_t n, hipStream_t st);
 void launch_debug_indices(const HashParams &hp, const uint8_t *d_seq, uint64_t len, uint64_t *d_out, hipStream_t st);
 void launch_synth_genomes(uint8_t *d_out, uint64_t n_genomes, uint64_t genome_len, uint64_t seed_base, hipStream_t st);
 void launch_synth_reads(uint8_t *d_out, uint64_t first, uint64_t n_reads, uint64_t read_len, const uint8_t *d_genomes,

@@ -35,7 +35,9 @@ struct ReadCtx {
 __device__ __forceinline__ bool verify_column(BlockLds &lds, uint32_t wave, const QueryArgs &a, const ReadCtx &rc,
                                               uint32_t col) {
     const uint32_t lane = lane_id();
-    const uint32_t cw = col >> 5, cb = col & 31u;
+    // `col` is a global column: group col / 2048 of the sliced matrix (a single group holds every column of a narrow tree)
+    const uint32_t *Sg = a.S_all + (uint64_t)(col >> 11) * a.group_stride;
+    const uint32_t cw = (col & 2047u) >> 5, cb = col & 31u;
     uint64_t hits = 0, seen = 0;
     for (uint64_t base = 0; base < rc.n; base += WIN_KMERS) {
         uint32_t cnt = (uint32_t)((rc.n - base) < WIN_KMERS ? (rc.n - base) : WIN_KMERS);
@@ -47,7 +49,7 @@ __device__ __forceinline__ bool verify_column(BlockLds &lds, uint32_t wave, cons
         it.init(h1, h2, a.hp);
         uint32_t ok = 1;
         for_each_probe(it, a.hp, [&](uint32_t idx) {
-            uint32_t v = valid ? a.S[(uint64_t)idx * a.rw + cw] : 0u;
+            uint32_t v = valid ? Sg[(uint64_t)idx * a.rw + cw] : 0u;
             ok &= (v >> cb);
         });
         uint64_t b = ballot64(valid && (ok & 1u));
@@ -466,8 +468,8 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             if (lane == 0) a.long_list[atomicAdd(a.n_long, 1u)] = (uint32_t)r;  // second launch (LONG)
             return;
         }
-        st_bytes += L;
-        if (rc.need == 0) {  // 0 >= 0 at every node: the read reaches and counts at every leaf
+        if (a.first_group) st_bytes += L;
+        if (rc.need == 0) {  // 0 >= 0 at every node: the read reaches and counts at every leaf (of every column group)
             ++st_all;
             if (a.allhit_flag && lane == 0) a.allhit_flag[r] = 1;
             return;
@@ -496,11 +498,16 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             int src = __ffsll((unsigned long long)b) - 1;
             uint32_t wv = bcast_u32(live, src);
             uint32_t bit = (uint32_t)__ffs((int)wv) - 1u;
-            uint32_t col = (uint32_t)src * 32u + bit;
+            const uint32_t col = a.col0 + (uint32_t)src * 32u + bit;  // global column
             if ((int)lane == src) live &= ~(1u << bit);
             ++st_cand;
-            // (reads of >= 2^37 k-mers cannot be deferred: 0xffffffff words are never available)
-            const uint32_t miss_need = (COUNTS && a.bucket_words) ? (rc.n < (1ull << 37) ? (uint32_t)((rc.n + 63) >> 6) : 0xffffffffu) : 0u;
+            // ancestors that are not provably supersets (guard columns) must pass as well: on the bucketed path each
+            // becomes a pair of its own, next to the leaf's pair in the same reservation, that names the leaf pair's slot
+            const uint32_t g_lo = a.guard_off[col], n_guard = a.guard_off[col + 1] - g_lo, n_slots = 1u + n_guard;
+            // (reads of >= 2^30 k-mers, or leaves with more guards than a reservation holds, cannot be deferred:
+            // 0xffffffff words are never available)
+            const uint32_t miss_one = (COUNTS && a.bucket_words) ? (rc.n < (1ull << 30) ? (uint32_t)((rc.n + 63) >> 6) : 0xffffffffu) : 0u;
+            const uint32_t miss_need = (miss_one == 0xffffffffu || n_slots > PAIR_CHUNK) ? (miss_one ? 0xffffffffu : 0u) : miss_one * n_slots;
             if (DEFER && COUNTS && a.bucket_words && miss_left < miss_need && miss_need != 0xffffffffu) {  // wave-uniform
                 const uint32_t want = miss_need > 1024u ? miss_need : 1024u;
                 unsigned long long got = 0;
@@ -508,8 +515,10 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
                 got = ((unsigned long long)bcast_u32((uint32_t)(got >> 32), 0) << 32) | bcast_u32((uint32_t)got, 0);
                 if (got + want <= a.miss_cap) miss_left = want;  // else: no room, this pair is certified inline
             }
-            if (DEFER && (!a.recs || o0 + rc.n <= a.rec_cap) && miss_left >= miss_need) {
-                if (pair_used == PAIR_CHUNK) {  // wave-uniform
+            if (DEFER && (!a.recs || o0 + rc.n <= a.rec_cap) && miss_left >= miss_need && n_slots <= PAIR_CHUNK && (n_guard == 0 || a.owner)) {
+                if (pair_used + n_slots > PAIR_CHUNK) {  // wave-uniform: the rest of the reservation is voided, a new one taken
+                    for (uint32_t i = pair_used + lane; i < PAIR_CHUNK; i += 64) a.pairs[pair_base + i] = make_uint2(0xffffffffu, 0xffffffffu);
+                    pair_used = PAIR_CHUNK;
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(a.pair_cursor, (unsigned long long)PAIR_CHUNK);
                     base = ((unsigned long long)bcast_u32((uint32_t)(base >> 32), 0) << 32) | bcast_u32((uint32_t)base, 0);
@@ -518,16 +527,18 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
                         pair_used = 0;
                     }
                 }
-                if (pair_used < PAIR_CHUNK) {
-                    if (lane == 0) {
-                        const uint32_t bkt = (col << a.sub_log2) | ((uint32_t)r & ((1u << a.sub_log2) - 1u));
-                        a.pairs[pair_base + pair_used] = make_uint2((uint32_t)r, col);
+                if (pair_used + n_slots <= PAIR_CHUNK) {
+                    if (lane < n_slots) {  // lane 0: the leaf's pair; lanes 1..: its guards
+                        const uint32_t c = lane == 0 ? col : a.guard_col[g_lo + lane - 1u];
+                        const uint32_t bkt = (c << a.sub_log2) | ((uint32_t)r & ((1u << a.sub_log2) - 1u));
+                        a.pairs[pair_base + pair_used + lane] = make_uint2((uint32_t)r, c);
+                        if (a.owner) a.owner[pair_base + pair_used + lane] = (uint32_t)(pair_base + pair_used);
                         atomicAdd(&a.bucket_cnt[bkt], 1u);
-                        if (COUNTS && a.bucket_words) atomicAdd(&a.bucket_words[bkt], miss_need);
+                        if (COUNTS && a.bucket_words) atomicAdd(&a.bucket_words[bkt], miss_one);
                     }
                     miss_left -= miss_need;
-                    ++pair_used;
-                    ++st_def;
+                    pair_used += n_slots;
+                    st_def += n_slots;
                     if (a.recs && !prepared) {  // hash the read once; every slice of the verify reuses the records
                         prepared = true;
                         // 150 bp reads at k = 20..23 have 128 + (1..3) k-mers: a third hashing pass for two or three
@@ -552,7 +563,7 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             bool pass = verify_column(lds, wave, a, rc, col);
             // ancestors that are not provably supersets must pass too (query.rs:119-141 visits children only with
             // reads that passed the parent)
-            for (uint32_t g = a.guard_off[col]; pass && g < a.guard_off[col + 1]; ++g)
+            for (uint32_t g = g_lo; pass && g < g_lo + n_guard; ++g)
                 pass = verify_column(lds, wave, a, rc, a.guard_col[g]);
             if (pass) {
                 ++st_hits;
@@ -647,9 +658,10 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
         for (uint32_t i = pair_used + lane; i < PAIR_CHUNK; i += 64) a.pairs[pair_base + i] = make_uint2(0xffffffffu, 0xffffffffu);
     // reads that pass every node (need == 0) count at every leaf (query.rs:143 reached through every path)
     if (st_all)
-        for (uint32_t c = lane; c < a.n_leaves; c += 64) atomicAdd(&a.counts[c], st_all);
+        for (uint32_t c = lane; c < a.n_leaves; c += 64) atomicAdd(&a.counts[a.col0 + c], st_all);
+    if (!a.first_group) st_all = 0;  // (statistics count a read once)
     for (int dd = 32; dd > 0; dd >>= 1) dense_bytes += __shfl_down(dense_bytes, dd);
-    st_bytes += bcast_u32((uint32_t)dense_bytes, 0) | ((unsigned long long)bcast_u32((uint32_t)(dense_bytes >> 32), 0) << 32);
+    if (a.first_group) st_bytes += bcast_u32((uint32_t)dense_bytes, 0) | ((unsigned long long)bcast_u32((uint32_t)(dense_bytes >> 32), 0) << 32);
     if (lane == 0) {
         if (st_cand) atomicAdd(&a.stats[ST_CANDIDATES], st_cand);
         if (st_hits) atomicAdd(&a.stats[ST_HITS], st_hits);
@@ -763,7 +775,8 @@ __global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, cons
                                                         uint64_t pair_cap, const uint32_t *off, uint32_t *cur, uint32_t sub_log2,
                                                         uint2 *sorted, uint4 *meta, const uint64_t *read_off,
                                                         const uint32_t *col_row, const uint32_t *words_off,
-                                                        uint32_t *words_cur, uint32_t *miss_pos, uint32_t kmer_size) {
+                                                        uint32_t *words_cur, uint32_t *miss_pos, uint32_t kmer_size,
+                                                        const uint32_t *owner, uint32_t *owner_sorted) {
     uint64_t n = *n_pairs_ptr;
     if (n > pair_cap) n = pair_cap;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -772,6 +785,7 @@ __global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, cons
         const uint32_t bkt = (p.y << sub_log2) | (p.x & ((1u << sub_log2) - 1u));
         uint32_t pos = off[bkt] + atomicAdd(&cur[bkt], 1u);
         sorted[pos] = p;
+        if (owner) owner_sorted[pos] = owner[i];
         if (meta) {
             uint64_t o0 = read_off[p.x], L = read_off[p.x + 1] - o0;
             meta[pos] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)L, col_row[p.y]);
@@ -785,9 +799,10 @@ __global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, cons
 void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
                            const uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t sub_log2, uint2 *sorted, uint4 *meta,
                            const uint64_t *read_off, const uint32_t *col_row, const uint32_t *words_off, uint32_t *words_cur,
-                           uint32_t *miss_pos, uint32_t kmer_size, int blocks, hipStream_t st) {
+                           uint32_t *miss_pos, uint32_t kmer_size, const uint32_t *owner, uint32_t *owner_sorted, int blocks,
+                           hipStream_t st) {
     hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, pairs, n_pairs_ptr, pair_cap, bucket_off, bucket_cur,
-                       sub_log2, sorted, meta, read_off, col_row, words_off, words_cur, miss_pos, kmer_size);
+                       sub_log2, sorted, meta, read_off, col_row, words_off, words_cur, miss_pos, kmer_size, owner, owner_sorted);
 }
 
 // ---- K2 for bucketed survivors: L2-resident filter slices ------------------------------------------------------------
@@ -1297,9 +1312,9 @@ void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
         attr_set = true;
     }
     const size_t lds_wide = (MAX_TILES + (size_t)a.n_tiles * 257) * 4, lds_wider = (MAX_TILES + (size_t)a.n_tiles * 513) * 4;
-    if (lds_wider <= 148 * 1024 && !getenv("PFQ_BIN_NARROW") && !getenv("PFQ_BIN_WIDE")) {
+    if (lds_wider <= 148 * 1024 && a.bin_shape == 0) {
         hipLaunchKernelGGL((k_tile_bin<16, 512>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_wider, st, a);
-    } else if (lds_wide <= 148 * 1024 && !getenv("PFQ_BIN_NARROW")) {
+    } else if (lds_wide <= 148 * 1024 && a.bin_shape != 1) {
         hipLaunchKernelGGL((k_tile_bin<16, 256>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_wide, st, a);
     } else {
         const size_t lds = (MAX_TILES + (size_t)a.n_tiles * 129) * 4;
@@ -1432,7 +1447,7 @@ void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st)
 // One block per leaf bucket: pairs that no slice failed are hits (mapped_reads += |pass|, query.rs:143).
 __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
     __shared__ unsigned long long s_cnt, s_bytes;
-    for (uint32_t c = blockIdx.x; c < a.n_leaves; c += gridDim.x) {
+    for (uint32_t c = a.c0 + blockIdx.x; c < a.c1; c += gridDim.x) {
         if (threadIdx.x == 0) { s_cnt = 0; s_bytes = 0; }
         __syncthreads();
         unsigned long long cnt = 0, bytes = 0;
@@ -1452,6 +1467,12 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
                 pass = n - missing >= need;
                 dirty += missing != 0;
             } else pass = !(a.fail[e] & 1u);
+            if (a.guards) {  // a guard that does not pass takes its leaf pair with it (query.rs:119-141: children are only
+                             // visited with the reads that passed the parent)
+                if (!pass) a.gfail[a.owner_sorted[e]] = 1u;
+                continue;
+            }
+            if (a.owner_sorted && a.gfail[a.owner_sorted[e]]) pass = false;
             if (pass) {
                 ++cnt;
                 bytes += need * a.hp.num_hashes * 32ull;
@@ -1478,8 +1499,8 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
     }
 }
 void launch_finalize(const FinalizeArgs &a, hipStream_t st) {
-    uint32_t blocks = a.n_leaves < 2048u ? a.n_leaves : 2048u;
-    if (blocks == 0) return;
+    uint32_t blocks = a.c1 - a.c0 < 2048u ? a.c1 - a.c0 : 2048u;
+    if (a.c1 <= a.c0) return;
     hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, st, a);
 }
 
@@ -1586,8 +1607,10 @@ void launch_superset(const uint64_t *bits, uint64_t n_words, const uint32_t *d_e
 
 // node-major -> sliced: wave = 64 columns x 4 consecutive u64 words; `__ballot` transposes 64 columns x 1 bit.
 __global__ void __launch_bounds__(256) k_transpose(const uint64_t *bits, uint64_t n_words, const uint32_t *col_row,
-                                                   uint32_t n_cols, uint32_t *S, uint32_t rw) {
+                                                   uint32_t n_cols, uint32_t *S, uint32_t rw, uint64_t group_stride) {
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, cg = blockIdx.y;
+    S += (uint64_t)(cg >> 5) * group_stride;  // 32 x 64 columns per group of the sliced matrix
+    const uint32_t cgl = cg & 31u;
     const uint32_t col = cg * 64u + lane;
     const bool has = col < n_cols;
     const uint64_t *src = bits + (uint64_t)(has ? col_row[col] : 0u) * n_words;
@@ -1608,19 +1631,26 @@ __global__ void __launch_bounds__(256) k_transpose(const uint64_t *bits, uint64_
                 uint64_t m = ballot64((v[j] >> b) & 1ull);
                 if (lane == b) keep = m;
             }
-            uint32_t *dst = S + (wi * 64 + lane) * (uint64_t)rw + cg * 2u;
-            if (cg * 2u < rw) dst[0] = (uint32_t)keep;
-            if (cg * 2u + 1u < rw) dst[1] = (uint32_t)(keep >> 32);
+            uint32_t *dst = S + (wi * 64 + lane) * (uint64_t)rw + cgl * 2u;
+            if (cgl * 2u < rw) dst[0] = (uint32_t)keep;
+            if (cgl * 2u + 1u < rw) dst[1] = (uint32_t)(keep >> 32);
         }
     }
 }
+__global__ void __launch_bounds__(256) k_add_counts(unsigned long long *dst, const unsigned long long *src, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+void launch_add_counts(unsigned long long *dst, const unsigned long long *src, uint32_t n, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_add_counts, dim3((n + 255) / 256), dim3(256), 0, st, dst, src, n);
+}
 void launch_transpose(const uint64_t *bits, uint64_t n_words, const uint32_t *d_col_row, uint32_t n_cols, uint32_t *S,
-                      uint32_t rw, hipStream_t st) {
+                      uint32_t rw, uint64_t group_stride, hipStream_t st) {
     if (!n_cols) return;
     uint32_t groups = (n_cols + 63) / 64;
     uint64_t bx = (n_words + 15) / 16;
     if (bx > 4096) bx = 4096;
-    hipLaunchKernelGGL(k_transpose, dim3((uint32_t)bx, groups), dim3(256), 0, st, bits, n_words, d_col_row, n_cols, S, rw);
+    hipLaunchKernelGGL(k_transpose, dim3((uint32_t)bx, groups), dim3(256), 0, st, bits, n_words, d_col_row, n_cols, S, rw, group_stride);
 }
 
 // ---- test / bench helpers ----------------------------------------------------------------------------------------------

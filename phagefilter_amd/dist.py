@@ -26,33 +26,75 @@ def all_reduce_counts(counts):
     return counts
 
 
+def _sync_stream(stream: int) -> None:
+    """Wait for the HIP stream the counters were exported / imported on (0 = the default stream)."""
+    import torch
+    if stream:
+        torch.cuda.ExternalStream(stream).synchronize()
+    else:
+        torch.cuda.default_stream().synchronize()
+
+
 def reduce_tree_counts(tree, device=None, stream: int = 0):
     """Export a tree's device counters, all-reduce them, import the global counts back (every rank ends with the
-    whole job's counts; rank 0 writes CLASSIFICATION.csv)."""
+    whole job's counts; rank 0 writes CLASSIFICATION.csv).  `stream` is the raw HIP stream of the query calls."""
     import torch
     n = int(tree.info().n_leaves)
     buf = torch.zeros(max(n, 1), dtype=torch.int64, device=device if device is not None else f"cuda:{tree.device}")
     tree.export_counts(buf.data_ptr(), stream)
-    torch.cuda.current_stream().synchronize()
+    _sync_stream(stream)          # the copy must have landed before the collective (another stream) reads the buffer
     all_reduce_counts(buf)
-    tree.import_counts(buf.data_ptr(), stream)
     torch.cuda.current_stream().synchronize()
+    tree.import_counts(buf.data_ptr(), stream)
+    _sync_stream(stream)
     return buf
 
 
+def check_disjoint_shards(first: int, n: int, total: int) -> None:
+    """Every rank's leaf range [first, first + n) must lie inside [0, total) and the ranges must not overlap: an
+    all-gather of the (first, n) pairs, checked on every rank.  No-op without a process group."""
+    import torch
+    import torch.distributed as dist
+    if not 0 <= first <= first + n <= total:
+        raise ValueError(f"shard range [{first}, {first + n}) outside the tree's {total} leaves")
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    mine = torch.tensor([first, n, total], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        mine = mine.cuda()
+    spans = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(spans, mine)
+    spans = sorted((int(s[0]), int(s[1]), int(s[2])) for s in spans)
+    if any(s[2] != total for s in spans):
+        raise ValueError(f"ranks disagree on the tree's leaf count: {spans}")
+    for (a0, an, _), (b0, _, _) in zip(spans, spans[1:]):
+        if an and a0 + an > b0:
+            raise ValueError(f"shard leaf ranges overlap: {spans}")
+
+
+def pad_and_reduce(local, first: int, total: int):
+    """Whole-tree counters from one shard's: a zero vector of the tree's `total` leaves with this rank's counters at
+    [first, first + len(local)), summed over the ranks by ONE all-reduce (the shards' ranges are disjoint, so the sum is
+    the concatenation; a shard held by no rank stays zero)."""
+    import torch
+    n = int(local.numel())
+    check_disjoint_shards(first, n, total)
+    full = torch.zeros(max(total, 1), dtype=torch.int64, device=local.device)
+    if n:
+        full[first:first + n] = local
+    all_reduce_counts(full)
+    return full
+
+
 def gather_shard_counts(tree, device=None, stream: int = 0):
-    """Subtree-sharded trees (BloomTree.load_subtree, one shard per rank, every rank classifies all reads): the
-    shards' leaf ranges are disjoint, so the whole tree's counters are one all-reduce of a zero-padded vector in
-    which each rank fills its own range [shard_first_leaf, shard_first_leaf + n_leaves)."""
+    """Subtree-sharded trees (BloomTree.load_subtree / build_balanced_subtree_device, one shard per rank, every rank
+    classifies all reads): the whole tree's counters on every rank.  `stream` is the raw HIP stream of the query calls."""
     import torch
     info = tree.info()
     n, first, total = int(info.n_leaves), int(info.shard_first_leaf), int(info.tree_leaves)
     dev = device if device is not None else f"cuda:{tree.device}"
-    full = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+    local = torch.zeros(n, dtype=torch.int64, device=dev)
     if n:
-        local = torch.zeros(n, dtype=torch.int64, device=dev)
         tree.export_counts(local.data_ptr(), stream)
-        torch.cuda.current_stream().synchronize()
-        full[first:first + n] = local
-    all_reduce_counts(full)
-    return full
+        _sync_stream(stream)
+    return pad_and_reduce(local, first, total)

@@ -102,6 +102,21 @@ class BloomTree:
                                                              largest_expected_genome, device, C.byref(h)))
         return cls(h, device)
 
+    @classmethod
+    def build_balanced_subtree_device(cls, d_genomes: int, genome_len: int, n_genomes: int, tax_ids: Sequence[str],
+                                      kmer_size: int, nbits: int, num_hashes: int, seed1: int, seed2: int, depth: int,
+                                      index: int, false_pos_rate: float = 0.001, largest_expected_genome: int = 1000000,
+                                      device: int = 0) -> "BloomTree":
+        """Subtree shard `index` of the depth-`depth` frontier of the balanced tree over all `n_genomes` genomes
+        (BASELINE config 5), built without the rest of the tree."""
+        ids = (C.c_char_p * max(len(tax_ids), 1))(*[t.encode() for t in tax_ids])
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().pfq_tree_build_balanced_subtree_device(d_genomes, genome_len, n_genomes, ids, kmer_size,
+                                                                     nbits, num_hashes, seed1, seed2, false_pos_rate,
+                                                                     largest_expected_genome, depth, index, device,
+                                                                     C.byref(h)))
+        return cls(h, device)
+
     def close(self) -> None:
         if self._h:
             _ffi.lib().pfq_tree_close(self._h)
@@ -145,6 +160,10 @@ class BloomTree:
         _ffi.check(_ffi.lib().pfq_leaf_counts_reset(self._h))
 
     # ---- measurement / test hooks
+    def set_option(self, name: str, value: Optional[str]) -> None:
+        """One tuning / test knob of this tree; None = the built-in choice."""
+        _ffi.check(_ffi.lib().pfq_set_option(self._h, name.encode(), None if value is None else str(value).encode()))
+
     def set_path(self, path: int) -> None:
         _ffi.check(_ffi.lib().pfq_set_path(self._h, path))
 
@@ -227,3 +246,11 @@ def get_leaf_counts(bloom_tree: BloomTree) -> List[Tuple[str, int]]:
 
 def save_leaf_counts(bloom_tree: BloomTree, path: str) -> None:
     bloom_tree.save_leaf_counts(path)
+
+
+def allreduce_counts(trees: Sequence[BloomTree]) -> int:
+    """Sum the per-leaf counters of replicas of one database (one per GPU, or several on one GPU) so that every replica
+    holds the totals; returns the number of RCCL ranks used.  The in-process counterpart of dist.all_reduce_counts."""
+    hs = (C.c_void_p * len(trees))(*[t._h for t in trees])
+    _ffi.check(_ffi.lib().pfq_trees_allreduce_counts(hs, len(trees)))
+    return int(_ffi.lib().pfq_last_allreduce_ranks())

@@ -47,7 +47,7 @@ def test_abi_exports_every_declared_symbol():
     from phagefilter_amd import _ffi
     L = _ffi.lib()
     header = open(os.path.join(ROOT, "include", "pfq.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char \*)\s*(pfq_[a-z_0-9]+)\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|void|uint32_t|const char \*)\s*(pfq_[a-z_0-9]+)\(", header, re.M))
     assert declared == set(_ffi.SYMBOLS), declared ^ set(_ffi.SYMBOLS)
     for s in declared:
         assert hasattr(L, s), s

@@ -179,14 +179,14 @@ def test_query_matches_oracle(gpu, n_genomes, k, nbits, h):
     for env, val, tile in (("PFQ_TILE_GB", "0", 1),                # no room for probe buckets: every pair takes the fallback
                            ("PFQ_TILE", "0", 0),                   # record-driven L2-sliced verify only
                            ("PFQ_RECORD_GB", "0", 0)):             # no probe records: re-hash per slice
-        os.environ[env] = val
+        gt.set_option(env, val)    # (the environment is read once per tree; pfq_set_option changes a knob afterwards)
         try:
             st = check_query(gt, ot, reads, 1.0, path=1)
             assert st.path == 1 and st.tile_mode == tile
             if env == "PFQ_TILE_GB":
                 assert 0 < st.n_fallback_pairs <= st.n_candidates and st.n_fallback_pairs >= 0.9 * st.n_candidates
         finally:
-            del os.environ[env]
+            gt.set_option(env, None)
     gt.close()
 
 
@@ -352,7 +352,8 @@ def test_config2_shape_64_leaves_k21(gpu):
         oh, _, _ = orc.query_batch_packed(ot, noisy, off, thr, threads=8)
         want = np.array(oracle_hits(ot, oh), dtype=np.int64).reshape(-1, 2)
         for env in ({}, {"PFQ_TILE_COUNTS": "1"}, {"PFQ_TILE_COUNTS": "1", "PFQ_TILE_ENTRIES": "6000000"}):
-            os.environ.update(env)
+            for key, val in env.items():
+                gt.set_option(key, val)
             try:
                 for call in range(2):
                     gt.reset_counts()
@@ -365,7 +366,7 @@ def test_config2_shape_64_leaves_k21(gpu):
                     assert np.array_equal(got, want), (thr, env, call)
             finally:
                 for key in env:
-                    del os.environ[key]
+                    gt.set_option(key, None)
     # clean reads at a threshold below 1: after one call the tile passes are chosen without being asked for
     for v in range(ot.n_nodes):
         ot.mapped_reads[v] = 0

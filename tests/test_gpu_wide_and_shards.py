@@ -1,0 +1,218 @@
+"""GPU parity tests of round 2: trees wider than one wave's row (column groups), reference-built trees whose internal
+node names collide (guard columns on the bucketed path), subtree shards built without the rest of the tree, one
+full-size shard of BASELINE config 5, and the in-process multi-replica count reduction (RCCL).
+Through the C ABI, against the CPU oracle; bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import pfq_format as fmt
+from oracle import pfq_oracle as orc
+from phagefilter_amd import BloomTree, PfqError, pack_reads
+from phagefilter_amd.query import allreduce_counts
+from test_gpu_parity import (RNG, _read_plan, check_query, gpu_tree, hits_of, make_reads, oracle_hits, oracle_tree,
+                             rand_dna)
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# more than 2048 leaf+guard columns: the sliced matrix is cut into column groups, the frontier runs once per group
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_genomes", [2049, 4100])
+def test_trees_wider_than_2048_columns(gpu, n_genomes):
+    k, nbits, h = 21, 65521, 4
+    genomes = [rand_dna(int(RNG.integers(150, 260))) for _ in range(n_genomes)]
+    genomes[2050 % n_genomes] = genomes[3]                       # twins in different column groups
+    genomes[n_genomes - 1] = genomes[7][:120] + genomes[n_genomes - 1][120:]
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    gt = gpu_tree(genomes, ids, k, nbits, h)
+    info = gt.info()
+    assert (info.n_leaves, info.superset_verified) == (n_genomes, 1)
+    reads = make_reads(genomes, 500, 100, 150, k) + make_reads(genomes, 20, 5, 400, k) + [genomes[3][:150], genomes[7][:100]]
+    for thr in (1.0, 0.5, 0.0, 0.97):
+        assert check_query(gt, ot, reads, thr, path=0).path == 0
+    for thr in (1.0, 0.5, 0.97):
+        assert check_query(gt, ot, reads, thr, path=1).path == 1
+    # pruned to internal "leaves" (still more than one group at depth 12 of the 4100-leaf tree)
+    ot.prune(12)
+    gt.prune_tree(12)
+    assert [t for t, _ in gt.get_leaf_counts()] == [t for t, _ in ot.leaf_counts()]
+    check_query(gt, ot, reads, 1.0, path=1)
+    check_query(gt, ot, reads, 0.4, path=0)
+    gt.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Internal_Node_<u16> names collide in reference-built trees -> two nodes alias one .bf -> parent ⊇ child
+# fails on some edges -> guard columns.  Those trees must stay on the bucketed (fast) path.
+# ---------------------------------------------------------------------------------------------------------------
+def _h4_tree(n_genomes, collisions, k=21, nbits=100003, h=5):
+    genomes = [rand_dna(int(RNG.integers(300, 500))) for _ in range(n_genomes)]
+    genomes[11] = genomes[10]
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    internal = [v for v in range(ot.n_nodes) if not ot.is_leaf(v)]
+    picks = RNG.choice(len(internal), size=2 * collisions, replace=False)
+    for a, b in zip(picks[:collisions], picks[collisions:]):
+        a, b = internal[int(a)], internal[int(b)]
+        # the earlier node's filter is replaced by a fresh one under the same key (bloom_tree.rs:294, cache.rs:83-87):
+        # both nodes alias ONE file afterwards, here the later node's
+        ot.bf_path[a] = ot.bf_path[b]
+        ot.filter_of[a] = ot.filter_of[b]
+    return genomes, ot, ids
+
+
+def test_colliding_internal_names_stay_on_the_bucketed_path(gpu, tmp_path):
+    genomes, ot, ids = _h4_tree(320, 32)                         # ~10 % of the 319 internal names collide
+    d = str(tmp_path / "db")
+    fmt.write_db(ot, d)
+    gt = BloomTree.load(d)
+    info = gt.info()
+    assert info.superset_verified == 0 and info.n_leaves == 320 and info.n_filters < info.n_nodes
+    reads = make_reads(genomes, 1500, 300, 150, 21) + make_reads(genomes, 40, 10, 600, 21)
+    for thr in (1.0, 0.6, 0.9):
+        st = check_query(gt, ot, reads, thr, path=1)
+        assert st.path == 1, thr                                  # guards are certified as pairs of their own
+        assert check_query(gt, ot, reads, thr, path=0).path == 0
+    st = check_query(gt, ot, reads, 1.0, path=1)
+    assert st.path == 1 and st.tile_mode == 1
+    for key, val in (("PFQ_TILE", "0"), ("PFQ_RECORD_GB", "0"), ("PFQ_TILE_ENTRIES", "20000")):
+        gt.set_option(key, val)
+        try:
+            assert check_query(gt, ot, reads, 1.0, path=1).path == 1
+            if key != "PFQ_RECORD_GB":
+                assert check_query(gt, ot, reads, 0.6, path=1).path == 1
+        finally:
+            gt.set_option(key, None)
+    gt.close()
+
+
+def test_guards_and_column_groups_together(gpu, tmp_path):
+    """A 2300-leaf tree with colliding names: guard columns live in the last column group, leaves in both."""
+    genomes, ot, ids = _h4_tree(2300, 40, nbits=65521, h=4)
+    d = str(tmp_path / "db")
+    fmt.write_db(ot, d)
+    gt = BloomTree.load(d)
+    assert gt.info().superset_verified == 0
+    reads = make_reads(genomes, 600, 100, 150, 21)
+    for thr in (1.0, 0.7):
+        assert check_query(gt, ot, reads, thr, path=1).path == 1
+        check_query(gt, ot, reads, thr, path=0)
+    gt.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: subtree shards built on the device without the rest of the tree
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_genomes,depth", [(13, 2), (32, 3), (21, 1), (5, 4)])
+def test_balanced_subtree_build_equals_shard_of_whole_tree(gpu, n_genomes, depth):
+    from hipbuf import DeviceBuffer
+    k, nbits, h, glen = 21, 50021, 5, 400
+    genomes_np = np.stack([np.frombuffer(orc.synth_genome(0x5EED0000 + i, glen), dtype=np.uint8) for i in range(n_genomes)])
+    genomes_np[4] = genomes_np[n_genomes - 1]                     # a read hitting leaves of two different shards
+    genomes = [g.tobytes() for g in genomes_np]
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    dg = DeviceBuffer.from_numpy(genomes_np.reshape(-1))
+    reads = make_reads(genomes, 200, 40, 150, k, errors=False)
+    seq, off = pack_reads(reads)
+    n_shards = 0
+    for thr in (1.0, 0.5):
+        for v in range(ot.n_nodes):
+            ot.mapped_reads[v] = 0
+        ohits, _, _ = orc.query_batch(ot, reads, thr)
+        want_counts, want_hits = ot.leaf_counts(), oracle_hits(ot, ohits)
+        got_counts, got_hits, i = [], [], 0
+        while True:
+            try:
+                sh = BloomTree.build_balanced_subtree_device(dg.ptr, glen, n_genomes, ids, k, nbits, h, 5, 10, depth, i)
+            except PfqError as e:
+                assert e.code == -1 and i > 0
+                break
+            info = sh.info()
+            osh, first = orc.subtree_shard(ot, depth, i)
+            assert (info.shard_first_leaf, info.tree_leaves, info.superset_verified) == (first, n_genomes, 1)
+            assert [t for t, _ in sh.get_leaf_counts()] == [t for t, _ in osh.leaf_counts()]
+            offs, leaves = sh.query_packed(seq, off, thr, want_hits=True)
+            got_counts += sh.get_leaf_counts()
+            got_hits += [(r, c + first) for r, c in hits_of(offs, leaves)]
+            sh.close()
+            i += 1
+        n_shards = i
+        assert got_counts == want_counts, (depth, thr)
+        assert sorted(got_hits) == want_hits, (depth, thr)
+    assert n_shards >= 2
+
+
+def test_config5_one_full_size_shard_2048_of_16384_leaves(gpu):
+    """BASELINE config 5 at its real geometry: shard 5 of the depth-3 frontier of the 16 384-leaf SBT (2048 leaves,
+    4095 + 3 filters of 71 887 936 bits = 36.8 GB node-major + 18.4 GB sliced), built on the device from the counter-based
+    genomes; reads drawn from ALL 16 384 genomes.  Size-independent properties (the oracle cannot hold this tree):
+    every positive read of the shard's leaves hits its source leaf, reads of other shards and random reads hit (almost)
+    nothing, counts are additive over a partition of the reads, independent of the query path, and idempotent."""
+    from hipbuf import DeviceBuffer, synchronize
+    from phagefilter_amd import _ffi
+    L = _ffi.lib()
+    n_g, glen, k, h, nbits, n_reads, shard = 16384, 50000, 21, 10, 71887936, 4 * 1024 * 1024, 5
+    ids = [f"G{i:05d}" for i in range(n_g)]
+    dg = DeviceBuffer(n_g * glen)
+    _ffi.check(L.pfq_synth_genomes_device(dg.ptr, n_g, glen, 0x5EED0000, None))
+    synchronize()
+    gt = BloomTree.build_balanced_subtree_device(dg.ptr, glen, n_g, ids, k, nbits, h, 0x0123456789ABCDEF,
+                                                 0xFEDCBA9876543210, 3, shard, 0.001, 5000000)
+    info = gt.info()
+    assert (info.n_leaves, info.shard_first_leaf, info.tree_leaves, info.superset_verified) == (2048, shard * 2048, n_g, 1)
+    assert info.n_nodes == 2 * n_g - 1 and info.n_filters == 4095 + 3
+    assert [t for t, _ in gt.get_leaf_counts()] == ids[shard * 2048:(shard + 1) * 2048]
+    dr = DeviceBuffer(n_reads * 150 + 64)
+    _ffi.check(L.pfq_synth_reads_device(dr.ptr, 0, n_reads, 150, dg.ptr, glen, n_g, 0x5EED1234, None))
+    off = DeviceBuffer.from_numpy(np.arange(n_reads + 1, dtype=np.uint64) * 150)
+    synchronize()
+    pos, leaf = _read_plan(0x5EED1234, 0, n_reads, n_g)
+    mine = pos & (leaf >= shard * 2048) & (leaf < (shard + 1) * 2048)
+    expect = np.bincount(leaf[mine] - shard * 2048, minlength=2048)
+    assert expect.sum() > n_reads // 20
+
+    def counts(path, lo, hi):
+        gt.reset_counts()
+        gt.set_path(path)
+        gt.query_device(dr.ptr + lo * 150, off.ptr, hi - lo, (hi - lo) * 150, 1.0, 0)
+        synchronize()
+        st = gt.last_stats()
+        assert st.path == path
+        return np.array([c for _, c in gt.get_leaf_counts()], dtype=np.int64)
+
+    whole = counts(1, 0, n_reads)
+    assert (whole >= expect).all()                                   # every positive read of the shard hits its leaf
+    assert 0 <= int(whole.sum() - expect.sum()) <= n_reads // 100000  # foreign and random reads: Bloom false positives only
+    half = n_reads // 2
+    assert np.array_equal(counts(1, 0, half) + counts(1, half, n_reads), whole)          # additive
+    thirds = [0, 1000003, 2500000, n_reads]
+    assert np.array_equal(sum(counts(0, a, b) for a, b in zip(thirds, thirds[1:])), whole)  # path/block independent
+    assert np.array_equal(counts(1, 0, n_reads), whole)                                  # idempotent
+    gt.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# replicas behind one process: pfq_trees_allreduce_counts (what `phage_filter query --devices` ends with)
+# ---------------------------------------------------------------------------------------------------------------
+def test_replicas_on_one_device_allreduce_to_single_tree_counts(gpu):
+    genomes = [rand_dna(700) for _ in range(9)]
+    ot, ids = oracle_tree(genomes, 21, 60013, 6)
+    reads = make_reads(genomes, 400, 80, 150, 21)
+    orc.query_batch(ot, reads, 0.7, want_hits=False)
+    want = ot.leaf_counts()
+    reps = [gpu_tree(genomes, ids, 21, 60013, 6) for _ in range(3)]
+    cuts = [0, 150, 151, len(reads)]                              # replica i classifies its own share of the reads
+    for rep, a, b in zip(reps, cuts, cuts[1:]):
+        seq, off = pack_reads(reads[a:b])
+        rep.query_packed(seq, off, 0.7)
+    ranks = allreduce_counts(reps)
+    assert ranks == 1                                             # three replicas, one device: a one-rank RCCL communicator
+    for rep in reps:
+        assert rep.get_leaf_counts() == want                      # every replica holds the job's totals
+    other = gpu_tree(genomes[:5], ids[:5], 21, 60013, 6)
+    with pytest.raises(PfqError):
+        allreduce_counts([reps[0], other])                        # not replicas of one database
+    with pytest.raises(PfqError):
+        allreduce_counts([reps[0], reps[0]])
+    for t in reps + [other]:
+        t.close()
