@@ -101,8 +101,10 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # Rehearsal knobs (not used by the driver): PFQ_BENCH_SAME_GPU=1 puts every rank on device 0 and
     # PFQ_BENCH_BACKEND=gloo replaces RCCL, so the N > 1 code path can be exercised on a one-GPU box.
-    dev_index = 0 if os.environ.get("PFQ_BENCH_SAME_GPU") == "1" else local_rank
-    backend = os.environ.get("PFQ_BENCH_BACKEND", "nccl")
+    # (RCCL refuses two ranks on one device — "Duplicate GPU detected" — so the same-GPU rehearsal defaults to gloo.)
+    same_gpu = os.environ.get("PFQ_BENCH_SAME_GPU") == "1"
+    dev_index = 0 if same_gpu else local_rank
+    backend = os.environ.get("PFQ_BENCH_BACKEND", "gloo" if same_gpu else "nccl")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:

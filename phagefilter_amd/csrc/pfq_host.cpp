@@ -151,6 +151,7 @@ struct pfq_tree {
     std::vector<uint32_t> col_row;   // column -> filter row
     std::vector<uint32_t> guard_off, guard_col;
     uint32_t rw = 1, rw_log2 = 0, n_cols = 0;
+    uint64_t leaf_cap = 0, guard_cap = 0;  // regions of the deferred-pair buffer
     uint32_t n_groups = 1;           // column groups of the sliced matrix (2048 columns each when there are several)
     uint64_t group_stride = 0;       // dwords per group: (n_words * 64 + 1) * rw
     DevBuf<uint32_t> d_S, d_col_row, d_guard_off, d_guard_col;
@@ -524,7 +525,7 @@ int build_layout(pfq_tree &t) {
 
 int ensure_scratch(pfq_tree &t, uint64_t n_reads, bool want_hits) {
     HIP_TRY(t.d_stats.ensure(pfq::ST_N));
-    HIP_TRY(t.d_cursors.ensure(8));
+    HIP_TRY(t.d_cursors.ensure(16));
     // two hits per read, or 1.3 x what recent blocks reported (a block that overflows is run again, see query_device)
     const uint64_t cap = (uint64_t)(std::max(2.0, 1.3 * t.hits_per_read) * (double)n_reads) + 1024;
     if (want_hits) {
@@ -564,7 +565,17 @@ bool ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads, bool with_guards) {
     // room for two candidates per read, or for 1.3 x what recent calls deferred (at most 24 per read: 40 B per slot);
     // + one partially used reservation per wave.  Pairs that do not fit are certified inline (exact, slow).
     const double per_read = std::min(24.0, std::max(2.0, 1.3 * t.pairs_per_read));
-    const uint64_t cap = (uint64_t)(per_read * (double)n_reads) + 32 * 4 * CLASSIFY_MAX_BLOCKS + 1024;
+    uint64_t cap = ((uint64_t)(per_read * (double)n_reads) + 32 * 4 * CLASSIFY_MAX_BLOCKS + 1024 + 31) & ~31ull;
+    // pairs deferred by k_classify: slots [0, leaf_cap); guard pairs (k_expand_guards): [leaf_cap, leaf_cap + guard_cap),
+    // sized by the tree's guards per leaf (what does not fit is certified inline there)
+    if (t.d_pairs.n && t.leaf_cap >= cap) cap = t.leaf_cap;  // (the buffers only grow)
+    t.leaf_cap = cap;
+    t.guard_cap = 0;
+    if (with_guards) {
+        const double per_leaf = (double)t.guard_col.size() / (double)std::max<size_t>(1, t.leaves.size());
+        t.guard_cap = ((uint64_t)((double)cap * std::min(4.0, std::max(0.25, per_leaf))) + 32 * 4 * 2048 + 31) & ~31ull;
+        cap += t.guard_cap;
+    }
     bool ok = soft_ensure(t.d_pairs, cap) && soft_ensure(t.d_sorted, cap) && soft_ensure(t.d_fail, cap) &&
               soft_ensure(t.d_bucket, 3 * ((size_t)t.n_cols << 6) + 2) &&  // up to 64 sub-buckets per column
               soft_ensure(t.d_queue, 128);
@@ -621,7 +632,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
         nb = nc << sub_log2;
         if (counts_mode) {  // thresholds < 1: every deferred pair owns ceil(n/64) words of k-mer miss bits that the slices OR into
             const uint64_t avg_len = n_reads ? total_bytes / n_reads : 0;
-            miss_cap = std::min<uint64_t>((t.d_pairs.n & ~31ull) * ((avg_len >> 6) + 2) + 4 * CLASSIFY_MAX_BLOCKS * 1024ull, 0xfffffff0ull);
+            miss_cap = std::min<uint64_t>((t.leaf_cap + t.guard_cap) * ((avg_len >> 6) + 2) + 4 * CLASSIFY_MAX_BLOCKS * 1024ull, 0xfffffff0ull);
             if (!(soft_ensure(t.d_miss_words, miss_cap) && soft_ensure(t.d_miss_pos, t.d_pairs.n) && soft_ensure(t.d_bucket_w, 3 * nb + 2)))
                 bucketed = false;
         }
@@ -631,7 +642,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     uint64_t hit_cap = t.d_hit_pairs.n;
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIP_TRY(hipMemsetAsync(t.d_stats.p, 0, pfq::ST_N * 8, st));
-        HIP_TRY(hipMemsetAsync(t.d_cursors.p, 0, 64, st));
+        HIP_TRY(hipMemsetAsync(t.d_cursors.p, 0, 128, st));
         if (want_hits) {
             HIP_TRY(hipMemsetAsync(t.d_allhit.p, 0, n_reads + 1, st));
             if (attempt == 0 && nl)
@@ -688,11 +699,10 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 t.last_sub_log2 = sub_log2;
                 uint32_t *cnt = t.d_bucket.p, *off = cnt + nb, *cur = off + nb + 1;
                 a.pairs = t.d_pairs.p;
-                a.pair_cap = t.d_pairs.n & ~31ull;  // whole reservations only (PAIR_CHUNK = 32)
+                a.pair_cap = t.leaf_cap;  // whole reservations only (PAIR_CHUNK = 32)
                 a.pair_cursor = t.d_cursors.p + 1;
                 a.bucket_cnt = cnt;
                 a.sub_log2 = sub_log2;
-                a.owner = with_guards ? t.d_owner.p : nullptr;
                 uint4 *recs = recs_possible ? t.d_recs.p : nullptr;
                 a.recs = recs;
                 a.rec_cap = recs ? t.d_recs.n : 0;
@@ -718,14 +728,29 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 128 * 4, st));
                 a.batch_tails = (recs && !counts_mode && kn.no_tail_batch <= 0) ? 1u : 0u;
                 PFQ_TRY(classify_groups(true));
+                pfq::GuardArgs ga{};
+                if (with_guards) {  // every guard of a deferred pair's leaf becomes a pair of its own (second region of the buffer)
+                    ga.pairs = t.d_pairs.p + t.leaf_cap;
+                    ga.cap = t.guard_cap;
+                    ga.cursor = t.d_cursors.p + 8;
+                    ga.slot0 = (uint32_t)t.leaf_cap;
+                    ga.owner = t.d_owner.p;
+                    ga.gfail = t.d_gfail.p;
+                    pfq::launch_expand_guards(a, ga, 2048, st);
+                }
                 if (a.batch_tails) pfq::launch_tail_records(a, 2048, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
                 pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nb, st);
                 if (counts_mode) pfq::launch_bucket_scan(cntw, offw, curw, (uint32_t)nb, st);
                 pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, sub_log2, t.d_sorted.p,
                                            recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, offw, curw,
-                                           counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size, a.owner,
-                                           with_guards ? t.d_owner_sorted.p : nullptr, 1024, st);
+                                           counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
+                                           with_guards ? t.d_owner.p : nullptr, with_guards ? t.d_owner_sorted.p : nullptr, 1024, st);
+                if (with_guards)
+                    pfq::launch_bucket_scatter(ga.pairs, ga.cursor, ga.cap, off, cur, sub_log2, t.d_sorted.p,
+                                               recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, offw, curw,
+                                               counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
+                                               t.d_owner.p + t.leaf_cap, t.d_owner_sorted.p, 256, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[2], st));
                 pfq::VerifyArgs v{};
                 v.hp = t.hp;
@@ -772,7 +797,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 t.last_tile_mode = 0;
                 if (tile_mode) {
                     // every read may survive with one candidate: (bases - (k-1) per read) * hashes * 1.125 + slack per bucket
-                    const uint64_t max_chunks = nc + (a.pair_cap >> pfq::CHUNK_PAIRS_LOG2) + 2;
+                    const uint64_t max_chunks = nc + ((t.leaf_cap + t.guard_cap) >> pfq::CHUNK_PAIRS_LOG2) + 2;
                     uint64_t want = (uint64_t)((double)total_bytes * t.num_hashes * 1.13 * std::max(1.0, t.pairs_per_read)) +
                                     max_chunks * n_tiles * 544ull;
                     if (want * 4 > tile_budget) want = tile_budget / 4;

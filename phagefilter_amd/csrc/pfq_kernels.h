@@ -35,7 +35,6 @@ struct QueryArgs {
     uint32_t n_leaves, n_cols;   // leaf columns of this group; leaf+guard columns of the tree
     const uint32_t *guard_off;   // [total leaves + 1] CSR into guard_col (may be all zeros), indexed by global leaf column
     const uint32_t *guard_col;   // global columns
-    uint32_t *owner;             // trees with guard columns: per pair slot, the slot of the leaf pair it belongs to (else nullptr)
     // results
     unsigned long long *counts;  // [n_leaves]  mapped_reads, accumulating (query.rs:143)
     uint2 *hit_pairs;            // (read, leaf) or nullptr
@@ -60,6 +59,17 @@ struct QueryArgs {
     unsigned long long *miss_cursor;   // words reserved so far
     uint64_t miss_cap;                 // words in the buffer
 };
+
+// Guard pairs (k_expand_guards): second region of the pair buffer, slots slot0 .. slot0 + cap of the whole buffer.
+struct GuardArgs {
+    uint2 *pairs;                // = pair buffer + slot0
+    uint64_t cap;                // slots in the region (whole reservations of 32)
+    unsigned long long *cursor;  // slots reserved so far
+    uint32_t slot0;              // index of the region's first slot in the whole pair buffer
+    uint32_t *owner;             // [whole pair buffer] slot of the leaf pair a slot belongs to (a leaf pair owns itself)
+    uint32_t *gfail;             // [whole pair buffer] indexed by the leaf pair's slot: a guard of it did not pass
+};
+void launch_expand_guards(const QueryArgs &a, const GuardArgs &ga, int blocks, hipStream_t st);
 
 struct ChunkDesc;
 struct VerifyArgs {

@@ -501,13 +501,8 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             const uint32_t col = a.col0 + (uint32_t)src * 32u + bit;  // global column
             if ((int)lane == src) live &= ~(1u << bit);
             ++st_cand;
-            // ancestors that are not provably supersets (guard columns) must pass as well: on the bucketed path each
-            // becomes a pair of its own, next to the leaf's pair in the same reservation, that names the leaf pair's slot
-            const uint32_t g_lo = a.guard_off[col], n_guard = a.guard_off[col + 1] - g_lo, n_slots = 1u + n_guard;
-            // (reads of >= 2^30 k-mers, or leaves with more guards than a reservation holds, cannot be deferred:
-            // 0xffffffff words are never available)
-            const uint32_t miss_one = (COUNTS && a.bucket_words) ? (rc.n < (1ull << 30) ? (uint32_t)((rc.n + 63) >> 6) : 0xffffffffu) : 0u;
-            const uint32_t miss_need = (miss_one == 0xffffffffu || n_slots > PAIR_CHUNK) ? (miss_one ? 0xffffffffu : 0u) : miss_one * n_slots;
+            // (guard columns — ancestors that are not provably supersets — of a deferred pair: k_expand_guards)
+            const uint32_t miss_need = (COUNTS && a.bucket_words) ? (rc.n < (1ull << 37) ? (uint32_t)((rc.n + 63) >> 6) : 0xffffffffu) : 0u;
             if (DEFER && COUNTS && a.bucket_words && miss_left < miss_need && miss_need != 0xffffffffu) {  // wave-uniform
                 const uint32_t want = miss_need > 1024u ? miss_need : 1024u;
                 unsigned long long got = 0;
@@ -515,10 +510,8 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
                 got = ((unsigned long long)bcast_u32((uint32_t)(got >> 32), 0) << 32) | bcast_u32((uint32_t)got, 0);
                 if (got + want <= a.miss_cap) miss_left = want;  // else: no room, this pair is certified inline
             }
-            if (DEFER && (!a.recs || o0 + rc.n <= a.rec_cap) && miss_left >= miss_need && n_slots <= PAIR_CHUNK && (n_guard == 0 || a.owner)) {
-                if (pair_used + n_slots > PAIR_CHUNK) {  // wave-uniform: the rest of the reservation is voided, a new one taken
-                    for (uint32_t i = pair_used + lane; i < PAIR_CHUNK; i += 64) a.pairs[pair_base + i] = make_uint2(0xffffffffu, 0xffffffffu);
-                    pair_used = PAIR_CHUNK;
+            if (DEFER && (!a.recs || o0 + rc.n <= a.rec_cap) && miss_left >= miss_need) {
+                if (pair_used == PAIR_CHUNK) {  // wave-uniform
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(a.pair_cursor, (unsigned long long)PAIR_CHUNK);
                     base = ((unsigned long long)bcast_u32((uint32_t)(base >> 32), 0) << 32) | bcast_u32((uint32_t)base, 0);
@@ -527,18 +520,16 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
                         pair_used = 0;
                     }
                 }
-                if (pair_used + n_slots <= PAIR_CHUNK) {
-                    if (lane < n_slots) {  // lane 0: the leaf's pair; lanes 1..: its guards
-                        const uint32_t c = lane == 0 ? col : a.guard_col[g_lo + lane - 1u];
-                        const uint32_t bkt = (c << a.sub_log2) | ((uint32_t)r & ((1u << a.sub_log2) - 1u));
-                        a.pairs[pair_base + pair_used + lane] = make_uint2((uint32_t)r, c);
-                        if (a.owner) a.owner[pair_base + pair_used + lane] = (uint32_t)(pair_base + pair_used);
+                if (pair_used < PAIR_CHUNK) {
+                    if (lane == 0) {
+                        const uint32_t bkt = (col << a.sub_log2) | ((uint32_t)r & ((1u << a.sub_log2) - 1u));
+                        a.pairs[pair_base + pair_used] = make_uint2((uint32_t)r, col);
                         atomicAdd(&a.bucket_cnt[bkt], 1u);
-                        if (COUNTS && a.bucket_words) atomicAdd(&a.bucket_words[bkt], miss_one);
+                        if (COUNTS && a.bucket_words) atomicAdd(&a.bucket_words[bkt], miss_need);
                     }
                     miss_left -= miss_need;
-                    pair_used += n_slots;
-                    st_def += n_slots;
+                    ++pair_used;
+                    ++st_def;
                     if (a.recs && !prepared) {  // hash the read once; every slice of the verify reuses the records
                         prepared = true;
                         // 150 bp reads at k = 20..23 have 128 + (1..3) k-mers: a third hashing pass for two or three
@@ -563,7 +554,7 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             bool pass = verify_column(lds, wave, a, rc, col);
             // ancestors that are not provably supersets must pass too (query.rs:119-141 visits children only with
             // reads that passed the parent)
-            for (uint32_t g = g_lo; pass && g < g_lo + n_guard; ++g)
+            for (uint32_t g = a.guard_off[col]; pass && g < a.guard_off[col + 1]; ++g)
                 pass = verify_column(lds, wave, a, rc, a.guard_col[g]);
             if (pass) {
                 ++st_hits;
@@ -684,6 +675,96 @@ void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int block
             hipLaunchKernelGGL((k_classify<false, true, true>), g, b, 0, st, a);
         } else hipLaunchKernelGGL((k_classify<false, false>), g, b, 0, st, a);
     }
+}
+
+// Guard columns on the bucketed path.  k_classify<DEFER> defers (read, leaf) pairs only; for trees with guard columns
+// (ancestors whose parent ⊇ child check failed: reference-built trees with colliding node names) this kernel
+// walks the deferred pairs and gives every guard of the pair's leaf a pair of its own, (read, guard column), in a second
+// region of the pair buffer.  owner[slot] names the leaf pair a slot belongs to (a leaf pair owns itself); k_finalize
+// lets a leaf pair pass only if none of its guard pairs failed (query.rs:119-141: children are visited only with the
+// reads that passed the parent).  A guard pair that finds no room is certified here, inline, and a failure is written
+// to gfail directly — results never depend on the capacities.  One wave per pair with guards; cold: trees whose edges
+// are all verified never launch it.
+__global__ void __launch_bounds__(256) k_expand_guards(QueryArgs a, GuardArgs ga) {
+    __shared__ BlockLds lds;
+    fill_complement(lds.comp);
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    unsigned long long n_slots = *a.pair_cursor;
+    if (n_slots > a.pair_cap) n_slots = a.pair_cap;
+    const uint64_t gw = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave, nw = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    unsigned long long g_base = 0;
+    uint32_t g_used = PAIR_CHUNK, miss_left = 0;
+    for (uint64_t s0 = gw * 64u; s0 < n_slots; s0 += nw * 64u) {
+        const uint64_t slot = s0 + lane;
+        uint2 p = make_uint2(0xffffffffu, 0xffffffffu);
+        if (slot < n_slots) p = a.pairs[slot];
+        const bool valid = p.y != 0xffffffffu;
+        if (valid) ga.owner[slot] = (uint32_t)slot;  // a leaf pair owns itself
+        const uint32_t g0 = valid ? a.guard_off[p.y] : 0u, ng = valid ? a.guard_off[p.y + 1] - g0 : 0u;
+        uint64_t todo = ballot64(ng != 0);
+        while (todo) {
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t r = bcast_u32(p.x, src), g_lo = bcast_u32(g0, src), n_guard = bcast_u32(ng, src);
+            const uint32_t own = (uint32_t)(s0 + (uint32_t)src);
+            const uint64_t o0 = a.off[r], L = a.off[r + 1] - o0;
+            ReadCtx rc;
+            rc.read = a.seq + o0;
+            rc.n = L - a.hp.k + 1;  // deferred reads have k-mers and 1 <= need <= n
+            rc.need = need_kmers(a.threshold, rc.n);
+            rc.maxmiss = rc.n - rc.need;
+            const uint32_t miss_one = a.bucket_words ? (uint32_t)((rc.n + 63) >> 6) : 0u;  // (deferred reads have < 2^30 k-mers)
+            for (uint32_t gg = 0; gg < n_guard; gg += PAIR_CHUNK) {
+                const uint32_t cnt = n_guard - gg < PAIR_CHUNK ? n_guard - gg : PAIR_CHUNK;
+                const uint32_t miss_need = miss_one * cnt;
+                if (a.bucket_words && miss_left < miss_need) {
+                    const uint32_t want = miss_need > 1024u ? miss_need : 1024u;
+                    unsigned long long got = 0;
+                    if (lane == 0) got = atomicAdd(a.miss_cursor, (unsigned long long)want);
+                    got = ((unsigned long long)bcast_u32((uint32_t)(got >> 32), 0) << 32) | bcast_u32((uint32_t)got, 0);
+                    if (got + want <= a.miss_cap) miss_left = want;
+                }
+                bool placed = false;
+                if (miss_left >= miss_need) {
+                    if (g_used + cnt > PAIR_CHUNK) {  // what is left of the reservation is voided, a new one taken
+                        for (uint32_t i = g_used + lane; i < PAIR_CHUNK; i += 64) ga.pairs[g_base + i] = make_uint2(0xffffffffu, 0xffffffffu);
+                        g_used = PAIR_CHUNK;
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(ga.cursor, (unsigned long long)PAIR_CHUNK);
+                        base = ((unsigned long long)bcast_u32((uint32_t)(base >> 32), 0) << 32) | bcast_u32((uint32_t)base, 0);
+                        if (base + PAIR_CHUNK <= ga.cap) {
+                            g_base = base;
+                            g_used = 0;
+                        }
+                    }
+                    if (g_used + cnt <= PAIR_CHUNK) {
+                        if (lane < cnt) {
+                            const uint32_t c = a.guard_col[g_lo + gg + lane];
+                            const uint32_t bkt = (c << a.sub_log2) | (r & ((1u << a.sub_log2) - 1u));
+                            ga.pairs[g_base + g_used + lane] = make_uint2(r, c);
+                            ga.owner[ga.slot0 + g_base + g_used + lane] = own;
+                            atomicAdd(&a.bucket_cnt[bkt], 1u);
+                            if (a.bucket_words) atomicAdd(&a.bucket_words[bkt], miss_one);
+                        }
+                        g_used += cnt;
+                        miss_left -= miss_need;
+                        placed = true;
+                    }
+                }
+                if (!placed) {  // no room: certify these guards here
+                    bool pass = true;
+                    for (uint32_t u = 0; pass && u < cnt; ++u) pass = verify_column(lds, wave, a, rc, a.guard_col[g_lo + gg + u]);
+                    if (!pass && lane == 0) ga.gfail[own] = 1u;
+                }
+            }
+        }
+    }
+    if (g_used < PAIR_CHUNK)
+        for (uint32_t i = g_used + lane; i < PAIR_CHUNK; i += 64) ga.pairs[g_base + i] = make_uint2(0xffffffffu, 0xffffffffu);
+}
+void launch_expand_guards(const QueryArgs &a, const GuardArgs &ga, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_expand_guards, dim3(blocks), dim3(256), 0, st, a, ga);
 }
 
 // Records of the last windows k_classify<DEFER> left out (has_batched_tail): one pass serves four deferred pairs,
