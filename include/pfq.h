@@ -159,6 +159,9 @@ int pfq_leaf_counts_export(pfq_tree *tree, uint64_t *d_dst, void *stream);
 int pfq_leaf_counts_import(pfq_tree *tree, const uint64_t *d_src, void *stream);
 int pfq_leaf_counts_reset(pfq_tree *tree);
 
+/* Number of HIP devices this process can use (`--devices all` of the CLI). */
+int pfq_device_count(int *n);
+
 /* Several GPUs behind one process (the block loop of main.rs:334-368 dealt over devices): `trees` are replicas of one
  * database (pfq_tree_open of the same directory, same pruning) on any devices, each fed its own share of the reads by its
  * own host thread.  This sums their per-leaf counters so that afterwards EVERY replica holds the job's totals

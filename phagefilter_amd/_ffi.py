@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libpfq.so")
 # every symbol include/pfq.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "pfq_tree_open", "pfq_tree_open_subtree", "pfq_tree_create", "pfq_tree_insert", "pfq_tree_build_balanced", "pfq_tree_build_balanced_device",
-    "pfq_tree_build_balanced_subtree_device", "pfq_trees_allreduce_counts", "pfq_last_allreduce_ranks", "pfq_set_option", "pfq_tree_save", "pfq_tree_info",
+    "pfq_tree_build_balanced_subtree_device", "pfq_trees_allreduce_counts", "pfq_last_allreduce_ranks", "pfq_device_count", "pfq_set_option", "pfq_tree_save", "pfq_tree_info",
     "pfq_tree_prune", "pfq_tree_close", "pfq_query_batch", "pfq_query_batch_device", "pfq_leaf_counts",
     "pfq_save_leaf_counts", "pfq_leaf_counts_export", "pfq_leaf_counts_import", "pfq_leaf_counts_reset",
     "pfq_last_stats", "pfq_set_path", "pfq_profile_begin", "pfq_profile_end", "pfq_debug_kmer_indices", "pfq_debug_node_filter", "pfq_synth_genomes_device",

@@ -830,32 +830,69 @@ int device_from_env() {
 int cmd_query(int argc, char **argv) {
     std::vector<Opt> opts = {{"reads", 'r', true}, {"out", 'o', true}, {"db-path", 'd', true}, {"threads", 't', true},
                              {"block-size-reads", 'b', true}, {"filter-threshold", 'f', true}, {"cache-size", 'c', true},
-                             {"search-depth", 0, true}, {"pos-filter", 0, false}, {"neg-filter", 0, false}, {"format", 'F', true}};
+                             {"search-depth", 0, true}, {"pos-filter", 0, false}, {"neg-filter", 0, false}, {"format", 'F', true},
+                             {"devices", 0, true}};
     Args a = parse(argc, argv, 2, opts);
     const std::string reads = req(a, "reads"), out = req(a, "out"), db = req(a, "db-path");
     const unsigned threads = (unsigned)std::min<uint64_t>(to_u64(opt(a, "threads", "4"), "threads"), 256);  // rayon pool size in the reference; here: parser workers
     (void)to_u64(opt(a, "cache-size", "10"), "cache-size");  // LRU of .bf files: the whole tree is resident in HBM
-    uint64_t block = to_u64(opt(a, "block-size-reads", "100"), "block-size-reads");
+    const uint64_t block = to_u64(opt(a, "block-size-reads", "100"), "block-size-reads");
     const float threshold = to_f32(opt(a, "filter-threshold", "1.0"), "filter-threshold");
     const bool pos = a.flags.count("pos-filter") != 0, neg = a.flags.count("neg-filter") != 0;
     const bool filtering = pos || neg;
     const FmtOverride ov = to_fmt(opt(a, "format", "auto"));
 
-    pfq_tree *tree = nullptr;
-    check(pfq_tree_open(db.c_str(), device_from_env(), &tree));
+    // --devices 0,1,..|all (or PFQ_DEVICES): one replica of the database per listed GPU, each fed by its own host thread;
+    // the per-genome counts are combined by one RCCL all-reduce at the end.  The reference has one rayon pool instead
+    // (main.rs:269-272); results do not depend on how the reads are dealt.
+    std::vector<int> devices;
+    {
+        std::string spec = opt(a, "devices", getenv("PFQ_DEVICES") ? getenv("PFQ_DEVICES") : "");
+        if (spec == "all") {
+            int n = 0;
+            check(pfq_device_count(&n));
+            for (int i = 0; i < n; ++i) devices.push_back(i);
+        } else if (!spec.empty()) {
+            size_t p0 = 0;
+            while (p0 <= spec.size()) {
+                size_t p1 = spec.find(',', p0);
+                if (p1 == std::string::npos) p1 = spec.size();
+                devices.push_back((int)to_u64(spec.substr(p0, p1 - p0), "devices"));
+                p0 = p1 + 1;
+            }
+        }
+        if (devices.empty()) devices.push_back(device_from_env());
+    }
+    const size_t n_dev = devices.size();
+    std::vector<pfq_tree *> trees(n_dev, nullptr);
+    {   // BloomTree::load per replica, side by side
+        std::vector<std::string> errs(n_dev);
+        std::vector<std::thread> th;
+        auto open_one = [&](size_t i) {
+            if (pfq_tree_open(db.c_str(), devices[i], &trees[i]) != PFQ_OK) errs[i] = std::string("libpfq: ") + pfq_last_error();
+        };
+        for (size_t i = 1; i < n_dev; ++i) th.emplace_back(open_one, i);
+        open_one(0);
+        for (auto &t : th) t.join();
+        for (auto &e : errs)
+            if (!e.empty()) die(e);
+    }
+    pfq_tree *tree = trees[0];
     printf("Querying reads...\n");
     printf("Filtering settings: positive=%s; negative=%s\n", pos ? "true" : "false", neg ? "true" : "false");
     if (a.val.count("search-depth")) {
         uint64_t depth = to_u64(a.val.at("search-depth"), "search-depth");
         if (!filtering) printf("If using a search depth, use a filtering flag (--pos-filter or --neg-filter, or both!)\n");
         printf("Search depth settings: %llu\n", (unsigned long long)depth);
-        check(pfq_tree_prune(tree, depth));
+        for (pfq_tree *t : trees) check(pfq_tree_prune(t, depth));
     }
     ReadQueue rq(reads, ov);
     // Page-locking costs ~1.7 s per GB here (hipHostMalloc), the pageable copy ~0.1 s per GB: pinned buffers only
     // pay off once every pooled buffer has been reused a few dozen times (inputs of >~ 10^9 reads).  Opt-in.
     g_pinned = getenv("PFQ_PINNED") && atoi(getenv("PFQ_PINNED")) != 0;
-    rq.start(filtering, threads);
+    // --block-size-reads 0: the reference's first block is empty (file_parser.rs:252-270: `0 > read_block.len()` is false),
+    // so its loop (main.rs:334-368) never runs: no read is parsed or classified, the outputs are created empty
+    if (block != 0) rq.start(filtering, threads);
 
     // create_and_overwrite_directory (main.rs:380-391): an existing output directory is deleted
     struct stat st;
@@ -882,168 +919,221 @@ int cmd_query(int argc, char **argv) {
     check(pfq_leaf_counts(tree, &tax, &cnt, &n_leaves));
     std::vector<std::string> leaf_names(tax, tax + n_leaves);
 
-    if (block == 0) block = 1;  // the reference would loop forever on empty blocks; treat 0 as 1
     const uint64_t t_loop0 = ReadQueue::now_ns();
-    uint64_t ns_gpu = 0, ns_out = 0, n_total = 0;
-    if (!filtering) {
+    std::atomic<uint64_t> ns_gpu{0}, ns_out{0}, n_total{0};
+    auto fail_from_thread = [](const char *what) { die(std::string("libpfq: ") + what); };
+    if (block == 0) {
+        // nothing to do: see above
+    } else if (!filtering) {
         // Counts only: the result does not depend on how the reads are cut into device calls (mapped_reads just
-        // accumulates, query.rs:143), so every parsed segment goes to the GPU as it is — no host-side copy.
-        while (Segment *sg = rq.next_segment()) {
-            const uint64_t n = sg->b.n();
-            if (n) {
-                sg->b.seq.resize(sg->b.seq.size() + 16);
-                const uint64_t tq0 = ReadQueue::now_ns();
-                check(pfq_query_batch(tree, sg->b.seq.data(), sg->b.off.data(), n, threshold, 0, nullptr));
-                ns_gpu += ReadQueue::now_ns() - tq0;
-                n_total += n;
+        // accumulates, query.rs:143), so every parsed segment goes to a GPU as it is — no host-side copy.  Segments are
+        // handed out in input order to whichever replica's thread asks next.
+        std::mutex qm;
+        bool done = false;
+        auto device_loop = [&](size_t d) {
+            while (true) {
+                Segment *sg = nullptr;
+                {
+                    std::lock_guard<std::mutex> lk(qm);
+                    if (done) return;
+                    sg = rq.next_segment();
+                    if (!sg) {
+                        done = true;
+                        return;
+                    }
+                    if (!sg->err.empty()) {  // malformed input: the reads before it are still classified, nothing after it
+                        rq.pending_error = sg->err;
+                        done = true;
+                    }
+                }
+                const uint64_t n = sg->b.n();
+                if (n) {
+                    sg->b.seq.resize(sg->b.seq.size() + 16);
+                    const uint64_t tq0 = ReadQueue::now_ns();
+                    if (pfq_query_batch(trees[d], sg->b.seq.data(), sg->b.off.data(), n, threshold, 0, nullptr) != PFQ_OK)
+                        fail_from_thread(pfq_last_error());
+                    ns_gpu += ReadQueue::now_ns() - tq0;
+                    n_total += n;
+                }
+                if (!sg->err.empty()) delete sg;
+                else rq.recycle(sg);
             }
-            if (!sg->err.empty()) {
-                rq.pending_error = sg->err;
-                delete sg;
-                break;
-            }
-            rq.recycle(sg);
-        }
+        };
+        std::vector<std::thread> th;
+        for (size_t d = 1; d < n_dev; ++d) th.emplace_back(device_loop, d);
+        device_loop(0);
+        for (auto &t : th) t.join();
     } else {
         // The device processes big batches; ResultMap semantics (ids merged per reference block, cleared per block,
         // main.rs:334-368) are applied per `block` consecutive reads so the outputs do not depend on the batch size.
-        const uint64_t batch_reads = std::max<uint64_t>(block, 1u << 20) / block * block;
-        // Batches are assembled on their own thread, one ahead of the GPU (double buffering).
-        Batch batches[2];
+        uint64_t batch_target = 1u << 20;
+        if (const char *e = getenv("PFQ_CLI_BATCH_READS")) batch_target = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // (tests: several batches from a small input)
+        const uint64_t batch_reads = std::max<uint64_t>(block, batch_target) / block * block;
+        // Batches are assembled on their own thread, ahead of the GPUs (one spare batch).  Batch k goes to whichever
+        // replica's thread asks next; outputs keep the input order: batch k's place in the two files is assigned when
+        // batch k-1's sizes are known, the bytes themselves are written side by side.
+        const size_t NB = n_dev + 1;
+        std::vector<Batch> batches(NB);
+        std::vector<int> ready(NB, 0);          // 0 = free for the assembler, 1 = filled
+        std::vector<uint64_t> batch_seq(NB, 0);  // which batch a filled slot holds
         std::mutex mu;
         std::condition_variable cv;
-        int ready[2] = {0, 0};   // 0 = free for the assembler, 1 = filled, 2 = filled and last
+        long long last_seq = -1;                 // sequence number of the last batch, once the assembler knows it
+        uint64_t next_take = 0, next_write = 0;
         std::thread parser([&] {
             bool more = true;
-            for (int i = 0; more; i ^= 1) {
+            for (uint64_t k = 0; more; ++k) {
+                const size_t slot = (size_t)(k % NB);
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return ready[i] == 0; });
+                    cv.wait(lk, [&] { return ready[slot] == 0; });
                 }
-                batches[i].clear();
-                more = rq.fill(batches[i], batch_reads, 3ull << 30);
+                batches[slot].clear();
+                more = rq.fill(batches[slot], batch_reads, 3ull << 30);
                 {
                     std::lock_guard<std::mutex> lk(mu);
-                    ready[i] = more ? 1 : 2;
+                    ready[slot] = 1;
+                    batch_seq[slot] = k;
+                    if (!more) last_seq = (long long)k;
                 }
                 cv.notify_all();
             }
         });
-        std::vector<std::string> pos_buf(threads), neg_buf(threads);
-        for (int i = 0;; i ^= 1) {
-            int state;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return ready[i] != 0; });
-                state = ready[i];
-            }
-            Batch &b = batches[i];
-            const uint64_t n = b.n();
-            if (n) {
-                b.seq.resize(b.seq.size() + 16);
-                pfq_hits hits{};
-                const uint64_t tq0 = ReadQueue::now_ns();
-                check(pfq_query_batch(tree, b.seq.data(), b.off.data(), n, threshold, PFQ_WANT_HITS, &hits));
-                const uint64_t tq1 = ReadQueue::now_ns();
-                ns_gpu += tq1 - tq0;
-                n_total += n;
-                // Blocks are independent (the ResultMap is cleared per block): worker w formats a contiguous range of
-                // blocks into its own buffers, which are then written in order.
-                const uint64_t n_blocks = (n + block - 1) / block;
-                const unsigned nw = (unsigned)std::min<uint64_t>(std::max(1u, threads), n_blocks);
-                // two phases per worker: format, then (offsets known) write its part of both files
-                std::vector<uint64_t> pos_at(nw + 1, 0), neg_at(nw + 1, 0);
-                std::mutex fm;
-                std::condition_variable fcv;
-                unsigned formatted = 0;
-                auto format_range = [&](unsigned w) {
-                    std::string &pb = pos_buf[w], &nb = neg_buf[w];
-                    pb.clear();
-                    nb.clear();
-                    std::unordered_map<std::string_view, std::vector<uint32_t>> result_map;  // read id -> leaves (result_map.rs:20-22)
-                    for (uint64_t blk = n_blocks * w / nw; blk < n_blocks * (w + 1) / nw; ++blk) {
-                        const uint64_t b0 = blk * block, b1 = std::min(n, b0 + block);
-                        result_map.clear();
-                        for (uint64_t r = b0; r < b1; ++r) {
-                            if (hits.offsets[r] == hits.offsets[r + 1]) continue;
-                            std::vector<uint32_t> &v = result_map[b.id(r)];
-                            v.insert(v.end(), hits.leaves + hits.offsets[r], hits.leaves + hits.offsets[r + 1]);
-                        }
-                        for (auto &kv : result_map) {  // a set of genomes per id; printed in leaf order
-                            std::sort(kv.second.begin(), kv.second.end());
-                            kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
-                        }
-                        for (uint64_t r = b0; r < b1; ++r) {
-                            auto it = result_map.empty() ? result_map.end() : result_map.find(b.id(r));
-                            const bool mapped = it != result_map.end();  // read_mapped
-                            if (mapped ? !pos : !neg) continue;
-                            std::string &line = mapped ? pb : nb;
-                            line += b.has_qual[r] ? '@' : '>';  // write_record (main.rs:394-404)
-                            line.append(b.id(r));
-                            if (mapped) {                        // get_ext_id: "{id} |{g1,g2}" (set order unspecified in the reference)
-                                line += " |";
-                                bool first = true;
-                                for (uint32_t leaf : it->second) {
-                                    if (!first) line += ',';
-                                    line += leaf_names[leaf];
-                                    first = false;
+        const unsigned fmt_threads_per_dev = std::max(1u, threads / (unsigned)n_dev);
+        auto device_loop = [&](size_t d) {
+            std::vector<std::string> pos_buf(fmt_threads_per_dev), neg_buf(fmt_threads_per_dev);
+            while (true) {
+                uint64_t k;
+                size_t slot;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    k = next_take++;
+                    slot = (size_t)(k % NB);
+                    cv.wait(lk, [&] { return (ready[slot] == 1 && batch_seq[slot] == k) || (last_seq >= 0 && (long long)k > last_seq); });
+                    if (last_seq >= 0 && (long long)k > last_seq) return;
+                }
+                Batch &b = batches[slot];
+                const uint64_t n = b.n();
+                unsigned nw = 1;
+                std::vector<uint64_t> pos_at(2, 0), neg_at(2, 0);
+                pos_buf[0].clear();
+                neg_buf[0].clear();
+                uint64_t tq1 = ReadQueue::now_ns();
+                if (n) {
+                    b.seq.resize(b.seq.size() + 16);
+                    pfq_hits hits{};
+                    const uint64_t tq0 = ReadQueue::now_ns();
+                    if (pfq_query_batch(trees[d], b.seq.data(), b.off.data(), n, threshold, PFQ_WANT_HITS, &hits) != PFQ_OK)
+                        fail_from_thread(pfq_last_error());
+                    tq1 = ReadQueue::now_ns();
+                    ns_gpu += tq1 - tq0;
+                    n_total += n;
+                    // Blocks are independent (the ResultMap is cleared per block): worker w formats a contiguous range of
+                    // blocks into its own buffers.
+                    const uint64_t n_blocks = (n + block - 1) / block;
+                    nw = (unsigned)std::min<uint64_t>(fmt_threads_per_dev, n_blocks);
+                    auto format_range = [&](unsigned w) {
+                        std::string &pb = pos_buf[w], &nb = neg_buf[w];
+                        pb.clear();
+                        nb.clear();
+                        std::unordered_map<std::string_view, std::vector<uint32_t>> result_map;  // read id -> leaves (result_map.rs:20-22)
+                        for (uint64_t blk = n_blocks * w / nw; blk < n_blocks * (w + 1) / nw; ++blk) {
+                            const uint64_t b0 = blk * block, b1 = std::min(n, b0 + block);
+                            result_map.clear();
+                            for (uint64_t r = b0; r < b1; ++r) {
+                                if (hits.offsets[r] == hits.offsets[r + 1]) continue;
+                                std::vector<uint32_t> &v = result_map[b.id(r)];
+                                v.insert(v.end(), hits.leaves + hits.offsets[r], hits.leaves + hits.offsets[r + 1]);
+                            }
+                            for (auto &kv : result_map) {  // a set of genomes per id; printed in leaf order
+                                std::sort(kv.second.begin(), kv.second.end());
+                                kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
+                            }
+                            for (uint64_t r = b0; r < b1; ++r) {
+                                auto it = result_map.empty() ? result_map.end() : result_map.find(b.id(r));
+                                const bool mapped = it != result_map.end();  // read_mapped
+                                if (mapped ? !pos : !neg) continue;
+                                std::string &line = mapped ? pb : nb;
+                                line += b.has_qual[r] ? '@' : '>';  // write_record (main.rs:394-404)
+                                line.append(b.id(r));
+                                if (mapped) {                        // get_ext_id: "{id} |{g1,g2}" (set order unspecified in the reference)
+                                    line += " |";
+                                    bool first = true;
+                                    for (uint32_t leaf : it->second) {
+                                        if (!first) line += ',';
+                                        line += leaf_names[leaf];
+                                        first = false;
+                                    }
+                                }
+                                line += '\n';
+                                const size_t s0 = line.size();
+                                line.append((const char *)b.seq.data() + b.off[r], b.off[r + 1] - b.off[r]);
+                                for (size_t c = s0; c < line.size(); ++c) line[c] = (char)toupper((unsigned char)line[c]);  // main.rs:347-349
+                                line += '\n';
+                                if (b.has_qual[r]) {
+                                    line += "+\n";
+                                    line.append(b.quality(r));
+                                    line += '\n';
                                 }
                             }
-                            line += '\n';
-                            const size_t s0 = line.size();
-                            line.append((const char *)b.seq.data() + b.off[r], b.off[r + 1] - b.off[r]);
-                            for (size_t c = s0; c < line.size(); ++c) line[c] = (char)toupper((unsigned char)line[c]);  // main.rs:347-349
-                            line += '\n';
-                            if (b.has_qual[r]) {
-                                line += "+\n";
-                                line.append(b.quality(r));
-                                line += '\n';
-                            }
                         }
+                    };
+                    std::vector<std::thread> fmt_threads;
+                    for (unsigned w = 1; w < nw; ++w) fmt_threads.emplace_back(format_range, w);
+                    format_range(0);
+                    for (auto &t : fmt_threads) t.join();
+                }
+                {   // my turn: the batches before this one have their places
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return next_write == k; });
+                    pos_at.assign(nw + 1, pos_size);
+                    neg_at.assign(nw + 1, neg_size);
+                    for (unsigned x = 0; x < nw; ++x) {
+                        pos_at[x + 1] = pos_at[x] + pos_buf[x].size();
+                        neg_at[x + 1] = neg_at[x] + neg_buf[x].size();
                     }
-                    {
-                        std::unique_lock<std::mutex> lk(fm);
-                        if (++formatted == nw) {  // last one in: every part's size is known
-                            pos_at[0] = pos_size;
-                            neg_at[0] = neg_size;
-                            for (unsigned x = 0; x < nw; ++x) {
-                                pos_at[x + 1] = pos_at[x] + pos_buf[x].size();
-                                neg_at[x + 1] = neg_at[x] + neg_buf[x].size();
-                            }
-                            fcv.notify_all();
-                        } else fcv.wait(lk, [&] { return formatted == nw; });
-                    }
-                    if (pos_fd >= 0) write_at(pos_fd, pb, pos_at[w]);
-                    if (neg_fd >= 0) write_at(neg_fd, nb, neg_at[w]);
-                };
-                std::vector<std::thread> fmt_threads;
-                for (unsigned w = 1; w < nw; ++w) fmt_threads.emplace_back(format_range, w);
-                format_range(0);
-                for (auto &t : fmt_threads) t.join();
-                pos_size = pos_at[nw];
-                neg_size = neg_at[nw];
+                    pos_size = pos_at[nw];
+                    neg_size = neg_at[nw];
+                    ++next_write;
+                }
+                cv.notify_all();
+                {   // the bytes: every formatter's part at its offset
+                    std::vector<std::thread> wr;
+                    auto write_part = [&](unsigned w) {
+                        if (pos_fd >= 0) write_at(pos_fd, pos_buf[w], pos_at[w]);
+                        if (neg_fd >= 0) write_at(neg_fd, neg_buf[w], neg_at[w]);
+                    };
+                    for (unsigned w = 1; w < nw; ++w) wr.emplace_back(write_part, w);
+                    write_part(0);
+                    for (auto &t : wr) t.join();
+                }
                 ns_out += ReadQueue::now_ns() - tq1;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ready[slot] = 0;
+                }
+                cv.notify_all();
             }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                ready[i] = 0;
-            }
-            cv.notify_all();
-            if (state == 2) break;
-        }
+        };
+        std::vector<std::thread> th;
+        for (size_t d = 1; d < n_dev; ++d) th.emplace_back(device_loop, d);
+        device_loop(0);
+        for (auto &t : th) t.join();
         parser.join();
     }
     if (getenv("PFQ_INGEST_TIMING")) {
         const double wall = (ReadQueue::now_ns() - t_loop0) * 1e-9;
-        fprintf(stderr, "query loop: %llu reads in %.3f s = %.2f M reads/s (pfq_query_batch %.3f s, output %.3f s)\n",
-                (unsigned long long)n_total, wall, n_total / wall * 1e-6, ns_gpu * 1e-9, ns_out * 1e-9);
+        fprintf(stderr, "query loop: %llu reads in %.3f s = %.2f M reads/s on %zu device(s) (pfq_query_batch %.3f s, output %.3f s)\n",
+                (unsigned long long)n_total.load(), wall, n_total.load() / wall * 1e-6, n_dev, ns_gpu.load() * 1e-9, ns_out.load() * 1e-9);
         rq.report_timing();
     }
     if (pos_fd >= 0) close(pos_fd);
     if (neg_fd >= 0) close(neg_fd);
     if (!rq.pending_error.empty()) die(rq.pending_error);  // the reads before the malformed record were processed
+    // per-genome counts of all replicas: one RCCL all-reduce (every replica then holds the totals); replica 0 writes the file
+    if (n_dev > 1) check(pfq_trees_allreduce_counts(trees.data(), (uint32_t)n_dev));
     check(pfq_save_leaf_counts(tree, (out + "/CLASSIFICATION.csv").c_str()));
-    pfq_tree_close(tree);
+    for (pfq_tree *t : trees) pfq_tree_close(t);
     printf("Finished.\n");
     return 0;
 }
@@ -1219,7 +1309,9 @@ void usage() {
             "  build           Builds the BloomTree.\n"
             "  add             Adds genomes to an already built BloomFilter.\n"
             "  build-balanced  Builds a balanced synthetic BloomTree on the GPU (benchmark databases)\n"
-            "  ingest-check    Parses reads like `query` and prints what was read (no GPU)\n");
+            "  ingest-check    Parses reads like `query` and prints what was read (no GPU)\n\n"
+            "query takes the reference's options, plus --devices <0,1,..|all>: one replica of the database per GPU, reads\n"
+            "dealt over them, per-genome counts combined by one RCCL all-reduce (default: device $PFQ_DEVICE or 0)\n");
 }
 
 }  // namespace

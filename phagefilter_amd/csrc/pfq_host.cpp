@@ -1725,6 +1725,17 @@ thread_local uint32_t g_last_ranks = 0;
 
 uint32_t pfq_last_allreduce_ranks(void) { return g_last_ranks; }
 
+int pfq_device_count(int *n) {
+    if (!n) return fail(PFQ_ERR_ARG, "null argument");
+    *n = 0;
+    if (hipGetDeviceCount(n) != hipSuccess || *n <= 0) {
+        (void)hipGetLastError();
+        *n = 0;
+        return fail(PFQ_ERR_DEVICE, "no HIP device available (libpfq has no CPU fallback)");
+    }
+    return PFQ_OK;
+}
+
 int pfq_trees_allreduce_counts(pfq_tree *const *trees, uint32_t n_trees) {
     g_last_ranks = 0;
     if (!trees || n_trees == 0) return fail(PFQ_ERR_ARG, "null argument");

@@ -298,3 +298,84 @@ def test_cli_accepts_benchmark_harness_invocations(tmp_path):
                         read_counter["_".join(line.strip(">").split(" ")[0].split("_")[:-1])] += 1
             want = Counter("_".join(reads[r][0].split("_")[:-1]) for r in sorted({r for r, _ in hits}))
             assert read_counter == want and sum(want.values()) >= 290
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# several replicas behind the CLI (`--devices`): dealer / merger checked against the single-device run byte for byte
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("filtering", [False, True])
+def test_cli_devices_two_replicas_equal_single_device(cli_db, tmp_path, filtering):
+    """`--devices 0,0`: two replicas of the database on one GPU, each fed by its own host thread; segments (counts
+    only) or batches (POS/NEG filtering) are dealt to whichever replica asks next, the per-genome counts are combined
+    by pfq_trees_allreduce_counts and replica 0 writes CLASSIFICATION.csv.  Every output file must equal the
+    single-device run's."""
+    base = [CLI, "query", "--reads", os.path.join(EX, "reads"), "--db-path", cli_db, "--filter-threshold", "0.7",
+            "--block-size-reads", "64", "--threads", "4"] + (["--pos-filter", "--neg-filter"] if filtering else [])
+    outs = {}
+    # small segments / batches so that both replicas get work
+    env = dict(os.environ, PFQ_INGEST_CHUNK_BYTES="20000", PFQ_INGEST_TIMING="1", PFQ_CLI_BATCH_READS="128")
+    for name, extra in (("one", []), ("two", ["--devices", "0,0"]), ("env", [])):
+        out = str(tmp_path / name)
+        e = dict(env, PFQ_DEVICES="0,0,0") if name == "env" else env
+        p = subprocess.run(base + ["--out", out] + extra, capture_output=True, text=True, env=e)
+        assert p.returncode == 0, p.stderr
+        assert ("on 1 device(s)" if name == "one" else f"on {2 if name == 'two' else 3} device(s)") in p.stderr
+        outs[name] = {f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out))}
+    gold = json.load(open(os.path.join(EX, "expected.json")))
+    assert outs["one"]["CLASSIFICATION.csv"].decode() == gold["expected"]["0.7"]["classification_csv"]
+    assert outs["two"] == outs["one"] and outs["env"] == outs["one"]
+    assert len(outs["one"]) == (3 if filtering else 1)
+    p = subprocess.run(base + ["--out", str(tmp_path / "bad"), "--devices", "0,7777"], capture_output=True, text=True)
+    assert p.returncode == 101 and "device" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_block_size_zero_processes_nothing(cli_db, tmp_path):
+    """--block-size-reads 0: the reference's first block is empty (file_parser.rs:252-270), its loop never runs
+    (main.rs:334-368): outputs are created empty, nothing is parsed — not even a malformed file is noticed."""
+    bad = tmp_path / "bad.fq"
+    bad.write_text("@r1\nACGT\n+\n")                              # truncated record
+    for src in (os.path.join(EX, "reads"), str(bad)):
+        out = str(tmp_path / "out")
+        p = subprocess.run([CLI, "query", "-r", src, "-o", out, "-d", cli_db, "-b", "0", "--pos-filter", "--neg-filter"],
+                           capture_output=True, text=True)
+        assert p.returncode == 0 and p.stdout.strip().endswith("Finished."), p.stderr
+        assert {f: os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)} == \
+            {"CLASSIFICATION.csv": 0, "POS_FILTERING.fq": 0, "NEG_FILTERING.fq": 0}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 1 end to end through the CLI's own greedy `build`
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_config1_greedy_build_then_query_examples(tmp_path):
+    """`phage_filter build` on the example genomes with the README's defaults (k = 20, fpr 0.001, largest genome 10^6;
+    main.rs:148-200: one leaf per FASTA record, greedy placement) and `phage_filter query` on the example reads: the
+    database equals the oracle's restatement of BloomTree::insert record by record, CLASSIFICATION.csv and the POS/NEG
+    files equal the oracle's query on that tree."""
+    db, out = str(tmp_path / "db"), str(tmp_path / "out")
+    p = subprocess.run([CLI, "build", "--genomes", os.path.join(EX, "genomes"), "--db-path", db, "--seed1", str(SEEDS[0]),
+                        "--seed2", str(SEEDS[1])], capture_output=True, text=True)
+    assert p.returncode == 0 and "Finished." in p.stdout, p.stderr
+    ids, seqs = [], []
+    for f in sorted(glob.glob(os.path.join(EX, "genomes", "*.fna")))[::-1]:       # files are popped from the back
+        for rid, seq in fasta_records(f):
+            ids.append(rid)
+            seqs.append(seq.encode())
+    ot = orc.build_greedy_tree(seqs, ids, 20, 0.001, 1000000, SEEDS[0], SEEDS[1])
+    lt = fmt.read_db(db)
+    assert fmt.encode_tree(lt) == fmt.encode_tree(ot)
+    for v in range(ot.n_nodes):
+        assert (lt.bits[lt.filter_of[v]] == ot.bits[ot.filter_of[v]]).all(), v
+    reads = example_reads()
+    for thr, block in (("1.0", 100), ("0.5", 1000)):
+        p = subprocess.run([CLI, "query", "--reads", os.path.join(EX, "reads"), "--out", out, "--db-path", db,
+                            "--filter-threshold", thr, "--block-size-reads", str(block), "--pos-filter", "--neg-filter"],
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        pos, neg = expected_filtering(ot, reads, float(thr), block)
+        assert open(os.path.join(out, "CLASSIFICATION.csv")).read() == ot.classification_csv()
+        assert len(ot.classification_csv()) > 0
+        assert parse_filter_file(os.path.join(out, "POS_FILTERING.fq"), True) == pos
+        assert parse_filter_file(os.path.join(out, "NEG_FILTERING.fq"), True) == neg
