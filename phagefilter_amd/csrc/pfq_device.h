@@ -275,6 +275,28 @@ struct RecordIter {
     }
 };
 
+// The same walk with one conditional subtraction per step: the step is g, or g2 = (g + d - 2^64 mod d) mod d when the 64-bit
+// add wrapped, both < d, so x + step < 2d.
+struct RecordIter1 {
+    uint32_t x, g, dg, cm, i0;  // dg = g2 - g (mod 2^32)
+    __device__ __forceinline__ void init(const uint4 &rec, uint32_t d, uint32_t dw) {
+        i0 = rec.x;
+        g = rec.y;
+        x = rec.z;
+        cm = rec.w;
+        uint32_t g2 = g + dw;
+        g2 = min(g2, g2 - d);
+        dg = g2 - g;
+    }
+    __device__ __forceinline__ uint32_t step(uint32_t d) {
+        uint32_t t = x + g + (dg & (0u - (cm & 1u)));
+        cm >>= 1;
+        t = min(t, t - d);
+        x = t;
+        return x;
+    }
+};
+
 // `(threshold * n as f32).ceil() as usize` (query.rs:48): IEEE f32 multiply (no contraction possible: single op),
 // ceil, Rust's saturating float->int cast (NaN -> 0).
 __device__ __forceinline__ uint64_t need_kmers(float threshold, uint64_t n) {

@@ -80,7 +80,7 @@ struct DevBuf {
 struct Knobs {
     long long record_gb = -1, tile_gb = -1, tile_entries = -1, slice_kb = -1;
     long long verify_blocks = -1, verify_chunk = -1, verify_sub = -1, verify_threads = -1, bin_blocks = -1, test_blocks = -1;
-    long long tile = -1, tile_counts = -1, no_tail_batch = -1, bin_narrow = -1, bin_wide = -1;
+    long long tile = -1, tile_counts = -1, no_tail_batch = -1, bin_narrow = -1, bin_wide = -1, bin_debug = -1;
 };
 struct KnobName {
     const char *name;
@@ -94,7 +94,7 @@ const KnobName KNOBS[] = {
     {"PFQ_BIN_BLOCKS", &Knobs::bin_blocks},     {"PFQ_TEST_BLOCKS", &Knobs::test_blocks},
     {"PFQ_TILE", &Knobs::tile},                 {"PFQ_TILE_COUNTS", &Knobs::tile_counts},
     {"PFQ_NO_TAIL_BATCH", &Knobs::no_tail_batch}, {"PFQ_BIN_NARROW", &Knobs::bin_narrow},
-    {"PFQ_BIN_WIDE", &Knobs::bin_wide},
+    {"PFQ_BIN_WIDE", &Knobs::bin_wide},         {"PFQ_BIN_DEBUG", &Knobs::bin_debug},
 };
 bool set_knob(Knobs &k, const char *name, const char *value) {
     for (const KnobName &kn : KNOBS)
@@ -161,7 +161,7 @@ struct pfq_tree {
     DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit, [1] pair, [2] tile entries, [3] lo: chunks, hi: flagged pairs, [4] long reads, [5] miss words, [6] dirty pairs, [7] lo: open pairs after the tile passes (thresholds < 1)
     DevBuf<uint32_t> d_entries, d_pair_chunk, d_leaf_chunk0, d_flag_list;  // LDS-tile certificates
     DevBuf<pfq::ChunkDesc> d_chunks;
-    DevBuf<unsigned int> d_gfill;
+    DevBuf<unsigned int> d_gfill, d_binq;
     uint32_t last_tile_mode = 0, last_passes = 1;
     DevBuf<uint2> d_hit_pairs, d_pairs, d_sorted;
     DevBuf<uint32_t> d_bucket, d_fail;  // bucket: cnt[n], off[n+1], cur[n]
@@ -803,10 +803,11 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                     if (want * 4 > tile_budget) want = tile_budget / 4;
                     if (kn.tile_entries >= 0) want = std::max<uint64_t>(1, (uint64_t)kn.tile_entries);  // tests: force passes
                     if (!(soft_ensure(t.d_entries, want) && soft_ensure(t.d_pair_chunk, t.d_pairs.n) && soft_ensure(t.d_flag_list, t.d_pairs.n) &&
-                          soft_ensure(t.d_leaf_chunk0, nc + 1) && soft_ensure(t.d_chunks, max_chunks) && soft_ensure(t.d_gfill, max_chunks * n_tiles))) {
+                          soft_ensure(t.d_leaf_chunk0, nc + 1) && soft_ensure(t.d_chunks, max_chunks) && soft_ensure(t.d_gfill, max_chunks * n_tiles) && soft_ensure(t.d_binq, 256))) {
                         tile_mode = false;  // not enough HBM for the probe buckets: stay with the record kernel
                     } else {
                         HIP_TRY(hipMemsetAsync(t.d_gfill.p, 0, max_chunks * n_tiles * 4, st));
+                        HIP_TRY(hipMemsetAsync(t.d_binq.p, 0, 256 * 4, st));
                         pfq::TileArgs ta{};
                         ta.hp = t.hp;
                         ta.bits = t.d_bits.p;
@@ -835,7 +836,8 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         int bin_blocks = 512, test_blocks = 512;
                         if (kn.bin_blocks >= 0) bin_blocks = std::max(1, (int)kn.bin_blocks);
                         if (kn.test_blocks >= 0) test_blocks = std::max(1, (int)kn.test_blocks);
-                        ta.bin_shape = kn.bin_narrow > 0 ? 1u : (kn.bin_wide > 0 ? 2u : 0u);
+                        ta.bin_shape = kn.bin_narrow > 0 ? (uint32_t)kn.bin_narrow : (kn.bin_wide > 0 ? 2u : 0u);
+                        ta.debug = kn.bin_debug > 0 ? (uint32_t)kn.bin_debug : 0u;
                         pfq::launch_tile_plan(ta, st);
                         // The probe buckets of all pairs may exceed the buffer (reads that pass many leaves): the plan
                         // spreads the chunks over passes that reuse it.  Their number is known on the device only; as
@@ -844,6 +846,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         const uint64_t n_passes = std::min<uint64_t>(std::max<uint64_t>(1, t.passes_hint), 256);  // (more: the record kernel takes the rest)
                         for (uint64_t p = 0; p < n_passes; ++p) {
                             ta.pass = (uint32_t)p;
+                            ta.bin_queue = t.d_binq.p + p;
                             pfq::launch_tile_bin(ta, bin_blocks, st);
                             if (p == 0 && ev) HIP_TRY(hipEventRecord(ev[3], st));
                             pfq::launch_tile_test(ta, test_blocks, st);

@@ -131,7 +131,8 @@ struct FinalizeArgs {
 // a block then loads one tile of one leaf into LDS and tests all its probes there.
 constexpr uint32_t TILE_LOG2 = 20;                 // bits per tile = 128 KiB of filter (one 1024-thread test block per CU;
                                                    // 64 KiB tiles, two blocks per CU: bin 11.4 / test 5.9 ms vs 10.8 / 5.9)
-constexpr uint32_t CHUNK_PAIRS_LOG2 = 12;          // pairs per chunk: local pair id and tile offset share one u32 entry
+constexpr uint32_t CHUNK_PAIRS_LOG2 = 10;          // pairs per chunk: local pair id and tile offset share one u32 entry; a chunk
+                                                   // is the work item of k_tile_bin (one block bins it alone)
 constexpr uint32_t MAX_TILES = 256;                // filters up to 2^27 bits take this path
 struct ChunkDesc {
     uint32_t row;      // filter row of the leaf
@@ -152,6 +153,7 @@ struct TileArgs {
     const uint32_t *bucket_off;  // [(n_leaves << sub_log2) + 1]
     uint32_t sub_log2, n_leaves, n_tiles;   // n_leaves: buckets = leaf + guard columns
     uint32_t bin_shape;          // 0 auto, 1 force the 8 x 128 build of k_tile_bin, 2 force 16 x 256
+    uint32_t debug;              // timing experiments only (results wrong): 1 no bucket stores, 2 no LDS binning, 4 no record loads
     ChunkDesc *chunks;           // [max_chunks]
     uint32_t max_chunks;
     uint32_t *leaf_chunk0;       // [n_leaves + 1] first chunk of each leaf (chunks of a leaf are contiguous)
@@ -160,7 +162,8 @@ struct TileArgs {
     unsigned long long *entry_cursor;  // virtual: pass = cursor / entry_cap, position in the pass = cursor % entry_cap
     uint64_t entry_cap;
     uint32_t *entries;
-    unsigned int *gfill;         // [max_chunks * n_tiles]
+    unsigned int *gfill;         // [max_chunks * n_tiles] entries (and padding) in every bucket, written by k_tile_bin
+    unsigned int *bin_queue;     // k_tile_bin of this pass: next chunk to take
     uint32_t *fail;              // bit 0: a probed bit was 0; bit 1: pair must be verified by the fallback kernel
     unsigned int *n_flagged;     // pairs with bit 1
     uint32_t *flag_list;         // [flag_cap] their sorted-pair indices

@@ -1101,10 +1101,10 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
     }
 }
 // ---- LDS-tile certificates ------------------------------------------------------------------------------------------------
-// (1) plan: one block per leaf cuts the leaf's sorted pairs into chunks of <= 4096, sizes the chunk's per-tile
-//     buckets from its k-mer count and reserves them; (2) bin: blocks walk the sorted pairs, regenerate every probe
-//     index from the records and append (local pair, offset in tile) to LDS bins, flushed per round to the
-//     (chunk, tile) buckets in full runs; (3) test: a block loads one tile of one leaf into LDS (128 KiB) and tests
+// (1) plan: one block per leaf cuts the leaf's sorted pairs into chunks of <= 1024, sizes the chunk's per-tile
+//     buckets from its k-mer count and reserves them; (2) bin: a block takes whole chunks, regenerates every probe
+//     index of their pairs from the records and appends (local pair, offset in tile) to LDS bins, flushed per round to
+//     the (chunk, tile) buckets in full runs; (3) test: a block loads one tile of one leaf into LDS (128 KiB) and tests
 //     all probes binned for it.  A probe found 0 sets bit 0 of the pair's fail word.  Whatever cannot be binned
 //     (bucket or entry buffer full) sets bit 1: those pairs are certified by k_verify_rec afterwards.
 __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
@@ -1133,9 +1133,10 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
         if (lane_id() == 0 && kmers) atomicAdd(&s_sum, kmers);
         __syncthreads();
         if (threadIdx.x == 0 && chunk < a.max_chunks) {
-            // mean probes per tile + 12.5 % + slack (a uniform hash stays far below; anything beyond falls back)
+            // mean probes per tile + 12.5 % + slack (a uniform hash stays far below; anything beyond falls back) + the padding
+            // of k_tile_bin's runs (up to 3 entries per round: a round brings >= 96 probes per tile, or 32 pairs)
             unsigned long long mean = (s_sum * a.hp.num_hashes + a.n_tiles - 1) / a.n_tiles;
-            uint32_t cap = (uint32_t)((mean + (mean >> 3) + 512 + 31) & ~31ull);
+            uint32_t cap = (uint32_t)((mean + (mean >> 3) + (mean >> 5) + 512 + 3 * ((n + 31) / 32 + 1) + 31) & ~31ull);
             unsigned long long need = (unsigned long long)cap * a.n_tiles;
             // (where the chunk's buckets go — pass and position in the reused buffer — is decided by k_tile_assign)
             const bool fits = need <= a.entry_cap;
@@ -1153,13 +1154,38 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
     }
 }
 // The bucket space is virtual: pass = position / entry_cap, place in the (reused) buffer = position % entry_cap.
-// One wave packs the chunks in order, 64 at a time: a chunk that does not fit the rest of the current pass starts the
-// next one, so no reservation straddles two passes.  (Reserving with atomics from the plan blocks was tried twice:
-// add-and-retry inflates the pass count without bound when a chunk nearly fills the buffer; compare-and-swap on one
-// word from 1024 blocks cost 5 ms.)  entry_cursor receives the end of the packing, for the host's pass count.
+// One wave packs the chunks in order: when everything fits one pass (the normal case) a chunk's place is the prefix sum of
+// the needs before it (wave scans, 64 chunks per step); else chunk after chunk, a chunk that does not fit the rest of
+// the current pass starting the next one, so that no reservation straddles two passes.  (Reserving with atomics from the
+// plan blocks was tried twice: add-and-retry inflates the pass count without bound when a chunk nearly fills the buffer;
+// compare-and-swap on one word from 1024 blocks cost 5 ms.)  entry_cursor receives the end of the packing, for the
+// host's pass count.
 __global__ void __launch_bounds__(64) k_tile_assign(TileArgs a) {
     const uint32_t lane = lane_id();
     const uint32_t n_chunks = *a.n_chunks < a.max_chunks ? *a.n_chunks : a.max_chunks;
+    unsigned long long total = 0;
+    for (uint32_t c = lane; c < n_chunks; c += 64) total += (unsigned long long)a.chunks[c].cap * a.n_tiles;
+    for (int dd = 32; dd > 0; dd >>= 1) total += __shfl_xor(total, dd);
+    if (total <= a.entry_cap) {  // one pass
+        unsigned long long run = 0;  // wave-uniform
+        for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            const uint32_t cap = c < n_chunks ? a.chunks[c].cap : 0u;
+            const unsigned long long need = (unsigned long long)cap * a.n_tiles;
+            unsigned long long incl = need;
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const unsigned long long o = __shfl_up(incl, dd);
+                if ((int)lane >= dd) incl += o;
+            }
+            if (cap) {
+                a.chunks[c].base = run + incl - need;
+                a.chunks[c].pass = 0;
+            }
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) *a.entry_cursor = run;
+        return;
+    }
     unsigned long long off = 0;  // wave-uniform
     uint32_t pass = 0;
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
@@ -1194,194 +1220,240 @@ void launch_tile_plan(const TileArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(k_tile_assign, dim3(1), dim3(64), 0, st, a);
 }
 
-// BIN_WAVES pairs are binned per round by one block, BIN_CAP LDS entries per tile and round (mean ~75 per 8 pairs at
-// 150 bp / 138 tiles, +6 sigma).  Two builds: 16 waves x 256 entries when the bins of all tiles fit the LDS (one block
-// per CU: twice as long runs per flush, half the rounds), else 8 x 128 (4 x 64 measured slower and spills more).
-// BIN_STRIDE is odd: the bins fill in step, so slot s of every tile would share a bank.
-constexpr uint32_t NO_PAIR = 0xfffffffeu;
+// k_tile_bin: a block takes whole chunks from a queue and bins every probe of the chunk's pairs by filter tile.
+//   * Exclusive chunks: the block alone fills the chunk's (chunk, tile) buckets, so the fill marks live in LDS and no
+//     global atomic is on the path (one per round and tile before: ~1.5 us of latency per round).
+//   * Rounds by k-mer budget: a round takes as many consecutive pairs (<= 32) as bring at most KB k-mers — 0.75 BIN_CAP
+//     probes per tile on average, and at most WPI windows of 64 k-mers per wave.  The k-mers of a round's pairs form ONE
+//     flattened index space that the waves walk in windows (a 150 bp read has 130 k-mers: one pair per wave would leave a
+//     third window with two busy lanes).  A read with more k-mers than the budget is binned over several rounds.
+//   * Branch-free appends: a lane without a probe counts in a counter of its own; the windows of an iteration advance
+//     together, so their LDS atomics are in flight together.
+//   * Two barriers per round; every wave flushes its own tiles (bin -> bucket as one 16-byte-aligned run, padded with
+//     ENTRY_PAD to a multiple of four entries) and clears their counters.
+// Whatever cannot be binned — an LDS bin or a bucket overflowing (skewed probe distributions), no room for the buckets —
+// flags the pair (bit 1 of its fail word, compact list) and k_verify_rec certifies exactly those pairs afterwards.
+constexpr uint32_t ENTRY_PAD = 0xffffffffu;  // no real entry: local pair ids have CHUNK_PAIRS_LOG2 <= 12 bits
+constexpr uint32_t ROUND_PAIRS = 32;         // lanes 0..31 of every wave hold the round's pairs
 __device__ __forceinline__ void flag_fallback(const TileArgs &a, uint32_t e) {
     if (!(atomicOr(&a.fail[e], 2u) & 2u)) {
         const uint32_t pos = atomicAdd(a.n_flagged, 1u);
         if (pos < a.flag_cap) a.flag_list[pos] = e;
     }
 }
+__device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, int src) {
+    return ((unsigned long long)bcast_u32((uint32_t)(v >> 32), src) << 32) | bcast_u32((uint32_t)v, src);
+}
+// Block barrier for data exchanged through LDS only.  __syncthreads() also waits for every outstanding global access of
+// the wave (s_waitcnt vmcnt(0)): with bucket stores and next-round loads in flight that is a memory round trip per
+// round (measured: 3.4 of k_tile_bin's 10.3 ms).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 template <uint32_t BIN_WAVES, uint32_t BIN_CAP>
 __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
-    constexpr uint32_t BIN_STRIDE = BIN_CAP + 1;
-    extern __shared__ uint32_t s_dyn[];   // cnt[MAX_TILES] then bins[n_tiles][BIN_CAP]
-    __shared__ uint32_t s_wc[BIN_WAVES], s_n[BIN_WAVES];
-    __shared__ uint32_t s_pos[MAX_TILES];
-    uint32_t *cnt = s_dyn, *bins = s_dyn + MAX_TILES;
+    constexpr uint32_t BIN_STRIDE = BIN_CAP + 4;  // rows stay 16-byte aligned; room for the padding of a full bin
+    constexpr uint32_t WPI = 2;                    // windows per wave and iteration
+    constexpr uint32_t DUMMY = MAX_TILES;          // counters MAX_TILES .. MAX_TILES + 63: where lanes without a probe count
+    extern __shared__ uint32_t s_dyn[];            // cnt[MAX_TILES + 64], fill[MAX_TILES], bins[n_tiles][BIN_STRIDE]
+    __shared__ uint32_t s_chunk;
+    uint32_t *cnt = s_dyn, *fillp = s_dyn + MAX_TILES + 64, *bins = fillp + MAX_TILES;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint32_t n_pairs = *a.n_pairs_ptr;
     const uint32_t d = (uint32_t)a.hp.nbits, dw = d - (uint32_t)a.hp.w64, k = a.hp.k, nh = a.hp.num_hashes;
-    // A block takes rounds of BIN_WAVES consecutive sorted pairs, one pair per wave; the pairs of a round that belong
-    // to the same chunk are binned together (normally all of them), chunk after chunk.  The round loop is software-
-    // pipelined: the next round's pair metadata is fetched while this round is binned, and this round's records
-    // are requested before the block-wide bookkeeping.
-    const uint32_t n_rounds = (n_pairs + BIN_WAVES - 1) / BIN_WAVES;
-    auto fetch = [&](uint32_t rd, uint32_t &chunk, uint4 &m) {
-        const uint32_t e = rd * BIN_WAVES + wave;
-        const bool have = rd < n_rounds && e < n_pairs;
-        chunk = have ? a.pair_chunk[e] : NO_PAIR;
-        m = have ? a.meta[e] : make_uint4(0, 0, 0, 0);  // (independent of the chunk load: both are in flight together)
-        // later passes know that there are several: drop the pairs of other passes before their records are requested
-        if (a.pass > 0 && chunk != NO_PAIR && (chunk == 0xffffffffu || a.chunks[chunk].pass != a.pass)) chunk = NO_PAIR;
-    };
-    uint32_t nxt_chunk;
-    uint4 nxt_meta;
-    fetch(blockIdx.x, nxt_chunk, nxt_meta);
-    uint32_t cached_id = NO_PAIR;
-    ChunkDesc dsc{};
-    for (uint32_t rd = blockIdx.x; rd < n_rounds; rd += gridDim.x) {
-        const uint32_t e = rd * BIN_WAVES + wave;
-        uint32_t my_chunk = nxt_chunk;
-        const uint4 m = nxt_meta;
-        const uint64_t o0 = ((uint64_t)m.y << 32) | m.x, n = my_chunk == NO_PAIR ? 0 : (uint64_t)m.z - k + 1;
-        const uint4 *rp = a.recs + o0;
-        // this round's first three windows of records
-        uint4 rec0[3];
-        bool valid0[3];
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-            const uint64_t q = 64u * w + lane;
-            valid0[w] = my_chunk != NO_PAIR && my_chunk != 0xffffffffu && q < n;
-            rec0[w] = valid0[w] ? rp[q] : make_uint4(0, 0, 0, 0);
-        }
-        fetch(rd + gridDim.x, nxt_chunk, nxt_meta);
-        if (my_chunk == 0xffffffffu) {  // chunk table full: fallback
-            if (lane == 0 && a.pass == 0) flag_fallback(a, e);
-            my_chunk = NO_PAIR;
-        }
+    const uint32_t n_chunks = *a.n_chunks < a.max_chunks ? *a.n_chunks : a.max_chunks;
+    uint32_t KB = (uint32_t)(((uint64_t)(BIN_CAP - BIN_CAP / 4) * a.n_tiles) / nh);
+    if (KB > WPI * BIN_WAVES * WIN_KMERS) KB = WPI * BIN_WAVES * WIN_KMERS;
+    if (KB == 0) KB = 1;
+    for (uint32_t t = threadIdx.x; t < MAX_TILES + 64; t += blockDim.x) cnt[t] = 0;
+    while (true) {
+        __syncthreads();  // everybody is done with the previous chunk
+        if (threadIdx.x == 0) s_chunk = atomicAdd(a.bin_queue, 1u);
+        for (uint32_t t = threadIdx.x; t < MAX_TILES; t += blockDim.x) fillp[t] = 0;
         __syncthreads();
-        if (lane == 0) {
-            s_wc[wave] = my_chunk;
-            s_n[wave] = my_chunk == NO_PAIR ? 0u : (uint32_t)(n < 0xffffffffull ? n : 0xffffffffull);
+        const uint32_t c = s_chunk;
+        if (c >= n_chunks) break;
+        const ChunkDesc dsc = a.chunks[c];
+        if (dsc.cap == 0) {  // no bucket space for this chunk: its pairs take the fallback
+            if (a.pass == 0)
+                for (uint32_t i = threadIdx.x; i < dsc.n; i += blockDim.x) flag_fallback(a, dsc.first + i);
+            continue;
         }
-        __syncthreads();
-        // lane w of every wave holds wave w's chunk and k-mer count: the per-chunk bookkeeping below is ballots and
-        // a 16-lane reduction instead of 2 x BIN_WAVES LDS reads per thread
-        const uint32_t c_l = lane < BIN_WAVES ? s_wc[lane] : NO_PAIR, n_l = lane < BIN_WAVES ? s_n[lane] : 0u;
-        uint32_t pending = (uint32_t)ballot64(c_l != NO_PAIR);
-        while (pending) {
-            const uint32_t cur = bcast_u32(c_l, __ffs((int)pending) - 1);
-            const uint32_t here = (uint32_t)ballot64(c_l == cur);
-            pending &= ~here;
-            for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) cnt[t] = 0;
-            if (cur != cached_id) {  // block-uniform
-                dsc = a.chunks[cur];
-                cached_id = cur;
+        if (dsc.pass != a.pass) continue;  // binned in another pass
+        uint32_t *bucket0 = a.entries + dsc.base;
+        // A round = pairs [p, p + P) of the chunk, K flattened k-mers (what is left of pair p after `koff`, then whole pairs).
+        // Lanes 0..31 of every wave hold the candidates p + lane (every wave computes the same); `incl` = inclusive prefix
+        // sums of their k-mer counts, qb = record index of flattened k-mer 0 of the lane's pair.
+        struct Round {
+            uint32_t p, P, K, incl;
+            unsigned long long koff, qb;
+            bool partial;
+        };
+        auto compose = [&](uint32_t p, unsigned long long koff, const uint4 &m) {
+            Round r;
+            r.p = p;
+            r.koff = koff;
+            const bool cand = lane < ROUND_PAIRS && p + lane < dsc.n;
+            const unsigned long long n64 = cand ? (unsigned long long)m.z - k + 1 - (lane == 0 ? koff : 0ull) : 0ull;
+            const uint32_t n_l = (uint32_t)(n64 > KB ? KB + 1u : n64);  // (more than the budget is all the same)
+            uint32_t incl = n_l;
+            for (uint32_t sft = 1; sft < ROUND_PAIRS; sft <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, (int)sft);
+                if (lane >= sft) incl += o;
             }
-            __syncthreads();
-            if (dsc.cap != 0 && dsc.pass != a.pass) continue;  // binned in another pass (block-uniform; bins untouched)
-            // The bins hold BIN_CAP entries per tile between two flushes: the k-mers of this chunk's pairs are binned
-            // in n_seg segments so that a segment brings about 0.75 * BIN_CAP probes per tile (one segment for reads
-            // of up to ~160 k-mers; long reads take several).  n_seg is block-uniform, segment lengths are per wave.
-            uint32_t sum_n = (c_l == cur) ? n_l : 0u, max_n = sum_n;  // (k-mer counts of a round stay far below 2^32)
-            for (int sft = 1; sft < (int)BIN_WAVES; sft <<= 1) {
-                sum_n += (uint32_t)__shfl_xor((int)sum_n, sft);
-                const uint32_t o = (uint32_t)__shfl_xor((int)max_n, sft);
-                max_n = o > max_n ? o : max_n;
-            }
-            const uint64_t kmers_here = bcast_u32(sum_n, 0);
-            max_n = bcast_u32(max_n, 0);
-            const uint32_t waves_here = (uint32_t)__popc(here);
-            const uint64_t seg_target = (uint64_t)(BIN_CAP - BIN_CAP / 4) * a.n_tiles;
-            // everything at once if it fits; else windows of whole 64-k-mer multiples per wave and segment
-            uint64_t seg_len = ~0ull;
-            uint32_t n_seg = 1;
-            if (dsc.cap && kmers_here * nh > seg_target) {
-                seg_len = (seg_target / ((uint64_t)waves_here * nh)) & ~(uint64_t)(WIN_KMERS - 1);
-                if (seg_len < WIN_KMERS) seg_len = WIN_KMERS;
-                n_seg = (uint32_t)((max_n + seg_len - 1) / seg_len);
-            }
-            // bins the k-mers [lo, hi) of my pair (whole 64-k-mer windows from lo on)
-            auto bin_range = [&](const uint64_t lo_k, const uint64_t hi_k) {
-                const uint32_t local = (e - dsc.first) << TILE_LOG2;
-                for (uint64_t g0 = lo_k; g0 < hi_k; g0 += 3 * WIN_KMERS) {
-                    uint4 rec[3];
-                    bool valid[3];
+            r.incl = incl;
+            r.P = (uint32_t)__popcll(ballot64(cand && incl <= KB));  // incl is monotone: a prefix of the candidates
+            r.partial = r.P == 0 && p < dsc.n;  // the first pair alone exceeds the budget: the next KB k-mers of it
+            if (r.partial) {
+                r.P = 1;
+                r.K = KB;
+            } else r.K = r.P ? bcast_u32(incl, (int)r.P - 1) : 0u;
+            r.qb = (((unsigned long long)m.y << 32) | m.x) + (lane == 0 ? koff : 0ull) - (unsigned long long)(incl - n_l);
+            return r;
+        };
+        auto load_meta = [&](uint32_t p) {
+            return (lane < ROUND_PAIRS && p + lane < dsc.n) ? a.meta[dsc.first + p + lane] : make_uint4(0, 0, 0, 0);
+        };
+        // the records of a round's windows of this wave: WPI windows of 64 flattened k-mers, window u = wave + u * BIN_WAVES
+        auto load_recs = [&](const Round &r, uint4 (&rec)[WPI], uint32_t (&local)[WPI], bool (&valid)[WPI]) {
 #pragma unroll
-                    for (int w = 0; w < 3; ++w) {
-                        const uint64_t q = g0 + 64u * w + lane;
-                        if (g0 == 0) {
-                            rec[w] = rec0[w];
-                            valid[w] = valid0[w] && q < hi_k;
-                        } else {
-                            valid[w] = q < hi_k;
-                            rec[w] = valid[w] ? rp[q] : make_uint4(0, 0, 0, 0);
-                        }
-                    }
-                    // branch-free append (an overflowing bin keeps overwriting its last slot and is detected at
-                    // flush time, cnt > BIN_CAP, when the round's pairs are sent to the fallback); the three
-                    // windows advance together so three LDS atomics are in flight per step
-                    RecordIter rit[3];
-#pragma unroll
-                    for (int w = 0; w < 3; ++w) rit[w].init(rec[w]);
-                    auto put3 = [&](uint32_t i0, uint32_t i1, uint32_t i2) {
-                        const uint32_t ix[3] = {i0, i1, i2};
-                        uint32_t tile[3], slot[3];
-#pragma unroll
-                        for (int w = 0; w < 3; ++w) tile[w] = ix[w] >> TILE_LOG2;
-#pragma unroll
-                        for (int w = 0; w < 3; ++w) slot[w] = valid[w] ? atomicAdd(&cnt[tile[w]], 1u) : 0u;
-#pragma unroll
-                        for (int w = 0; w < 3; ++w)
-                            if (valid[w]) bins[tile[w] * BIN_STRIDE + min(slot[w], BIN_CAP - 1u)] = local | (ix[w] & ((1u << TILE_LOG2) - 1u));
-                    };
-                    put3(rit[0].i0, rit[1].i0, rit[2].i0);
-                    if (nh > 1) put3(rit[0].g, rit[1].g, rit[2].g);
-                    if (nh > 2) put3(rit[0].x, rit[1].x, rit[2].x);
-                    for (uint32_t i = 3; i < nh; ++i) {
-                        const uint32_t s0 = rit[0].step(d, dw), s1 = rit[1].step(d, dw), s2 = rit[2].step(d, dw);
-                        put3(s0, s1, s2);
+            for (uint32_t u = 0; u < WPI; ++u) {
+                const uint32_t f0 = (wave + u * BIN_WAVES) * WIN_KMERS, f = f0 + lane;
+                valid[u] = f < r.K;
+                // the pair of flattened k-mer f: j0 = the pair of the window's first k-mer, then the pair ends inside the window
+                uint32_t j0 = (uint32_t)__popcll(ballot64(lane < r.P && r.incl <= f0));
+                if (j0 >= r.P) j0 = r.P ? r.P - 1 : 0;  // (window past the end: no valid lane)
+                uint32_t j = j0;
+                unsigned long long qb = bcast_u64(r.qb, (int)j0);
+                for (uint32_t t = j0; t + 1 < r.P; ++t) {
+                    const uint32_t e = bcast_u32(r.incl, (int)t);
+                    if (e > f0 + 63u) break;
+                    const unsigned long long qn = bcast_u64(r.qb, (int)t + 1);
+                    if (f >= e) {
+                        j = t + 1;
+                        qb = qn;
                     }
                 }
-            };
-            // flush: every tile's bin goes to its (chunk, tile) bucket as one run; all reservations of the round
-            // are made by one atomic instruction (one lane per tile), not tile after tile
-            auto flush = [&]() {
-                bool over = false;
-                for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) {
-                    over = over || cnt[t] > BIN_CAP;
-                    const uint32_t c = cnt[t] < BIN_CAP ? cnt[t] : BIN_CAP;
-                    s_pos[t] = c ? atomicAdd(&a.gfill[(uint64_t)cur * a.n_tiles + t], c) : 0u;
-                }
-                if (__syncthreads_or(over) && my_chunk == cur && lane == 0) flag_fallback(a, e);  // an LDS bin overflowed
-
-                for (uint32_t t = wave; t < a.n_tiles; t += BIN_WAVES) {
-                    const uint32_t c = cnt[t] < BIN_CAP ? cnt[t] : BIN_CAP;
-                    if (c == 0) continue;
-                    const uint32_t pos = s_pos[t];
-                    uint32_t *dst = a.entries + dsc.base + (uint64_t)t * dsc.cap;
-                    // what fits is written (k_tile_test reads min(fill, cap) entries: every slot below cap must hold a
-                    // real probe); the pairs whose probes are dropped — bucket full — take the fallback
-                    const uint32_t room = pos < dsc.cap ? dsc.cap - pos : 0u, wr = c < room ? c : room;
-                    for (uint32_t i = lane; i < wr; i += 64) dst[pos + i] = bins[t * BIN_STRIDE + i];
-                    for (uint32_t i = wr + lane; i < c; i += 64) flag_fallback(a, dsc.first + (bins[t * BIN_STRIDE + i] >> TILE_LOG2));
-                }
-            };
-            if (dsc.cap == 0) {  // no bucket space for this chunk
-                if (my_chunk == cur && lane == 0 && a.pass == 0) flag_fallback(a, e);
-            } else if (n_seg == 1) {  // the common case, kept free of the segment arithmetic
-                if (my_chunk == cur) bin_range(0, n);
-                __syncthreads();
-                flush();
-            } else {
-                for (uint32_t seg = 0; seg < n_seg; ++seg) {
-                    if (seg) {
-                        for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) cnt[t] = 0;
-                        __syncthreads();
-                    }
-                    const uint64_t lo_k = (uint64_t)seg * seg_len;
-                    if (my_chunk == cur && lo_k < n) bin_range(lo_k, lo_k + seg_len < n ? lo_k + seg_len : n);
-                    __syncthreads();
-                    flush();
-                    __syncthreads();
-                }
+                rec[u] = valid[u] ? a.recs[qb + f] : make_uint4(0, 0, 0, 0);  // (no k-mer: every index 0, see `put`)
+                local[u] = (r.p + j) << TILE_LOG2;
             }
-            __syncthreads();
+        };
+        // Software pipeline over the rounds: while round r is binned, the records of round r + 1 and the pair metadata of
+        // round r + 2 are in flight (all waves of the block move in step, so a load issued where it is needed would expose
+        // its whole latency every round: 3 of 10 ms).
+        uint4 m_nxt = load_meta(0);
+        Round cur = compose(0, 0, m_nxt);
+        uint4 rec[WPI];
+        uint32_t local[WPI];
+        bool valid[WPI];
+        load_recs(cur, rec, local, valid);
+        {
+            const uint32_t p1 = cur.partial ? cur.p : cur.p + cur.P;
+            m_nxt = load_meta(p1);
         }
+        while (cur.p < dsc.n) {
+            const uint32_t p1 = cur.partial ? cur.p : cur.p + cur.P;
+            const Round nxt = compose(p1, cur.partial ? cur.koff + KB : 0ull, m_nxt);
+            uint4 rec_n[WPI];
+            uint32_t local_n[WPI];
+            bool valid_n[WPI];
+            load_recs(nxt, rec_n, local_n, valid_n);
+            m_nxt = load_meta(nxt.partial ? nxt.p : nxt.p + nxt.P);
+            if (!(a.debug & 2u)) {
+                RecordIter1 rit[WPI];
+                uint32_t cbase[WPI];  // counter index of tile 0 for this lane
+#pragma unroll
+                for (uint32_t u = 0; u < WPI; ++u) {
+                    rit[u].init(rec[u], d, dw);
+                    cbase[u] = valid[u] ? 0u : DUMMY + lane;
+                }
+                // Branch-free appends: a lane without a k-mer walks index 0 (a zero record), counts in a counter of its own
+                // and writes nothing; the windows advance together, so that their LDS atomics are in flight together.  An
+                // overflowing bin keeps overwriting its last slot and is detected at flush time (cnt > BIN_CAP).
+                auto put = [&](const uint32_t (&ix)[WPI]) {
+                    uint32_t tile[WPI], slot[WPI];
+#pragma unroll
+                    for (uint32_t u = 0; u < WPI; ++u) tile[u] = ix[u] >> TILE_LOG2;
+#pragma unroll
+                    for (uint32_t u = 0; u < WPI; ++u) slot[u] = atomicAdd(&cnt[cbase[u] + tile[u]], 1u);
+#pragma unroll
+                    for (uint32_t u = 0; u < WPI; ++u)
+                        if (valid[u]) bins[tile[u] * BIN_STRIDE + min(slot[u], BIN_CAP - 1u)] = local[u] | (ix[u] & ((1u << TILE_LOG2) - 1u));
+                };
+                uint32_t ix[WPI];
+#pragma unroll
+                for (uint32_t u = 0; u < WPI; ++u) ix[u] = rit[u].i0;
+                put(ix);
+                if (nh > 1) {
+#pragma unroll
+                    for (uint32_t u = 0; u < WPI; ++u) ix[u] = rit[u].g;
+                    put(ix);
+                }
+                if (nh > 2) {
+#pragma unroll
+                    for (uint32_t u = 0; u < WPI; ++u) ix[u] = rit[u].x;
+                    put(ix);
+                }
+                for (uint32_t i = 3; i < nh; ++i) {
+#pragma unroll
+                    for (uint32_t u = 0; u < WPI; ++u) ix[u] = rit[u].step(d);
+                    put(ix);
+                }
+            }
+            lds_barrier();  // every probe of the round is in its bin
+            // (the next round's records are taken over BEFORE the bucket stores are issued: waiting for them afterwards would
+            // also wait for every store, which are younger in the same counter)
+            const uint32_t flush_p = cur.p, flush_P = cur.P;
+            cur = nxt;
+#pragma unroll
+            for (uint32_t u = 0; u < WPI; ++u) {
+                rec[u] = rec_n[u];
+                local[u] = local_n[u];
+                valid[u] = valid_n[u];
+            }
+            // flush: every bin goes to its bucket as one run at the fill mark (kept in LDS: the block owns the chunk).  Sixteen
+            // lanes per tile, four tiles per wave and pass, the 16-byte reads of a lane issued together: one LDS round trip
+            // per batch instead of one per copy instruction (the block's waves flush in step, nothing else hides the latency).
+            for (uint32_t t0 = wave * 4u; t0 < a.n_tiles; t0 += BIN_WAVES * 4u) {
+                const uint32_t t = t0 + (lane >> 4), sl = lane & 15u;
+                const bool have = t < a.n_tiles;
+                const uint32_t cn = have ? cnt[t] : 0u, pos = have ? fillp[t] : 0u;
+                const uint32_t cc = cn < BIN_CAP ? cn : BIN_CAP, c4 = (cc + 3u) & ~3u;
+                uint32_t *row = bins + t * BIN_STRIDE;
+                if (sl < c4 - cc) row[cc + sl] = ENTRY_PAD;
+                __builtin_amdgcn_wave_barrier();
+                // what fits is written (k_tile_test reads min(fill, cap) entries: every slot below cap must hold an entry
+                // or padding); the pairs whose probes are dropped — bucket full — take the fallback
+                const uint32_t room = pos < dsc.cap ? dsc.cap - pos : 0u, wr = c4 < room ? c4 : room;
+                uint32_t *dst = bucket0 + (uint64_t)(have ? t : 0u) * dsc.cap + pos;
+                constexpr uint32_t FB = 5;  // 16-byte reads in flight per lane: two batches cover a full bin (516 entries / 64)
+                const uint32_t wr_eff = (a.debug & 1u) ? 0u : wr;
+                for (uint32_t i0 = sl * 4u; i0 < wr; i0 += 64u * FB) {
+                    uint4 v[FB];
+#pragma unroll
+                    for (uint32_t u = 0; u < FB; ++u)  // (unconditional, clamped into the row: nothing waits for a branch)
+                        v[u] = *reinterpret_cast<const uint4 *>(row + min(i0 + u * 64u, BIN_STRIDE - 4u));
+#pragma unroll
+                    for (uint32_t u = 0; u < FB; ++u)  // (keeps the compiler from sinking every read next to its store)
+                        asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+#pragma unroll
+                    for (uint32_t u = 0; u < FB; ++u)
+                        if (i0 + u * 64u < wr_eff) *reinterpret_cast<uint4 *>(dst + i0 + u * 64u) = v[u];
+                }
+                for (uint32_t i = wr + sl; i < cc; i += 16) flag_fallback(a, dsc.first + (row[i] >> TILE_LOG2));
+                if (cn > BIN_CAP) {  // the LDS bin overflowed: whose probes were lost is unknown
+                    for (uint32_t i = sl; i < flush_P; i += 16) flag_fallback(a, dsc.first + flush_p + i);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (have && sl == 0 && cn) {
+                    fillp[t] = pos + c4;
+                    cnt[t] = 0;
+                }
+            }
+            lds_barrier();  // bins and counters are free again
+        }
+        for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) a.gfill[(uint64_t)c * a.n_tiles + t] = fillp[t];
     }
 }
 void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
@@ -1392,79 +1464,108 @@ void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<16, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    const size_t lds_wide = (MAX_TILES + (size_t)a.n_tiles * 257) * 4, lds_wider = (MAX_TILES + (size_t)a.n_tiles * 513) * 4;
-    if (lds_wider <= 148 * 1024 && a.bin_shape == 0) {
-        hipLaunchKernelGGL((k_tile_bin<16, 512>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_wider, st, a);
-    } else if (lds_wide <= 148 * 1024 && a.bin_shape != 1) {
-        hipLaunchKernelGGL((k_tile_bin<16, 256>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_wide, st, a);
+    auto lds_of = [&](size_t cap) { return (2 * MAX_TILES + 64 + (size_t)a.n_tiles * (cap + 4)) * 4; };
+    if (a.bin_shape == 3 && lds_of(256) <= 74 * 1024) {  // experiment: two 8-wave blocks per CU
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<8, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipLaunchKernelGGL((k_tile_bin<8, 256>), dim3(blocks), dim3(8 * 64), lds_of(256), st, a);
+    } else if (lds_of(512) <= 148 * 1024 && a.bin_shape == 0) {
+        hipLaunchKernelGGL((k_tile_bin<16, 512>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_of(512), st, a);
+    } else if (lds_of(256) <= 148 * 1024 && a.bin_shape != 1) {
+        hipLaunchKernelGGL((k_tile_bin<16, 256>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_of(256), st, a);
     } else {
-        const size_t lds = (MAX_TILES + (size_t)a.n_tiles * 129) * 4;
-        hipLaunchKernelGGL((k_tile_bin<8, 128>), dim3(blocks), dim3(8 * 64), lds, st, a);
+        hipLaunchKernelGGL((k_tile_bin<8, 128>), dim3(blocks), dim3(8 * 64), lds_of(128), st, a);
     }
 }
 
-constexpr uint32_t TEST_LOADS = 4;  // 16-byte entry loads in flight per thread (8 measured slower: 6.1 vs 5.9 ms)
+constexpr uint32_t TEST_LOADS = 4;   // 16-byte entry loads in flight per thread (8 measured slower: 6.1 vs 5.9 ms)
+constexpr uint32_t TEST_GROUP = 32;  // chunks of a leaf whose buckets are streamed as one sequence
 __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     extern __shared__ uint32_t s_tile[];  // 2^TILE_LOG2 bits
+    __shared__ uint32_t s_pref[TEST_GROUP + 1], s_first[TEST_GROUP], s_misc[2];
+    __shared__ unsigned long long s_base[TEST_GROUP];
     const uint32_t tile_words = 1u << (TILE_LOG2 - 5);
     const uint64_t n_words32 = a.n_words * 2;
     const uint64_t n_tasks = (uint64_t)a.n_leaves * a.n_tiles;
     const uint32_t n_chunks = *a.n_chunks < a.max_chunks ? *a.n_chunks : a.max_chunks;
     for (uint64_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
         const uint32_t leaf = (uint32_t)(task / a.n_tiles), t = (uint32_t)(task % a.n_tiles);
-        uint32_t ch = a.leaf_chunk0[leaf];
-        if (ch == 0xffffffffu) continue;  // no pairs for this leaf
+        const uint32_t ch0 = a.leaf_chunk0[leaf];
+        if (ch0 == 0xffffffffu) continue;  // no pairs for this leaf
         bool loaded = false;  // the tile is loaded when the first chunk of this pass is met (block-uniform)
-        for (; ch < n_chunks && a.chunks[ch].leaf == leaf; ++ch) {
-            const ChunkDesc dsc = a.chunks[ch];
-            if (!dsc.cap || dsc.pass != a.pass) continue;
-            if (!loaded) {
+        for (uint32_t g0 = ch0;; g0 += TEST_GROUP) {
+            // The buckets (this tile's) of up to 32 chunks of the leaf, described once in LDS and then streamed as ONE
+            // sequence of entries: a chunk's bucket alone (~20 k entries) would leave the block's 16 k-entry steps half idle.
+            __syncthreads();  // the previous group / task is done with the LDS
+            if (threadIdx.x < 64) {
+                const uint32_t i = threadIdx.x, c = g0 + i;
+                ChunkDesc dsc{};
+                const bool mine = i < TEST_GROUP && c < n_chunks && (dsc = a.chunks[c], dsc.leaf == leaf);
+                const bool usable = mine && dsc.cap != 0 && dsc.pass == a.pass;
+                uint32_t fill = usable ? a.gfill[(uint64_t)c * a.n_tiles + t] : 0u;
+                if (fill > dsc.cap) fill = dsc.cap;
+                uint32_t incl = fill;
+                for (uint32_t sft = 1; sft < TEST_GROUP; sft <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_up((int)incl, (int)sft);
+                    if (i >= sft) incl += o;
+                }
+                if (i < TEST_GROUP) {
+                    s_pref[i + 1] = incl;
+                    s_first[i] = dsc.first;
+                    s_base[i] = dsc.base + (uint64_t)t * dsc.cap;
+                }
+                const uint64_t um = ballot64(usable), mm = ballot64(mine);
+                if (i == 0) {
+                    s_pref[0] = 0;
+                    s_misc[0] = (uint32_t)__popcll(mm);                                                    // chunks of the leaf in this group
+                    s_misc[1] = um ? bcast_u32(dsc.row, __ffsll((unsigned long long)um) - 1) : 0xffffffffu;  // the leaf's filter row
+                }
+            }
+            __syncthreads();
+            const uint32_t n_mine = s_misc[0], row = s_misc[1], total = s_pref[TEST_GROUP];
+            if (total && !loaded) {
                 loaded = true;
-                __syncthreads();
-                // the leaf's tile: words [t * tile_words, ...) of its filter row (zero beyond the filter's end)
-                const uint32_t row = dsc.row;
+                // the leaf's tile: words [t * tile_words, ...) of its filter row (zero beyond the filter's end); filter rows
+                // are only 8-byte aligned: 8-byte loads, all sixteen of a thread in flight
                 const uint32_t *src = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)row * a.n_words);
                 const uint64_t w0 = (uint64_t)t * tile_words;
-                // filter rows are only 8-byte aligned: 8-byte loads, eight in flight per thread
-                for (uint32_t i0 = threadIdx.x * 2; i0 < tile_words; i0 += blockDim.x * 16) {
-                    uint2 v[8];
+                uint2 v[16];
 #pragma unroll
-                    for (uint32_t u = 0; u < 8; ++u) {
-                        const uint32_t i = i0 + u * blockDim.x * 2;
-                        v[u] = (i < tile_words && w0 + i + 1 < n_words32) ? *reinterpret_cast<const uint2 *>(src + w0 + i) : make_uint2(0, 0);
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < 8; ++u) {
-                        const uint32_t i = i0 + u * blockDim.x * 2;
-                        if (i < tile_words) *reinterpret_cast<uint2 *>(s_tile + i) = v[u];
-                    }
+                for (uint32_t u = 0; u < 16; ++u) {
+                    const uint32_t i = threadIdx.x * 2 + u * 2048u;
+                    v[u] = (w0 + i + 1 < n_words32) ? *reinterpret_cast<const uint2 *>(src + w0 + i) : make_uint2(0, 0);
                 }
+#pragma unroll
+                for (uint32_t u = 0; u < 16; ++u) *reinterpret_cast<uint2 *>(s_tile + threadIdx.x * 2 + u * 2048u) = v[u];
                 __syncthreads();
             }
-            uint32_t fill = a.gfill[(uint64_t)ch * a.n_tiles + t];
-            if (fill > dsc.cap) fill = dsc.cap;
-            const uint32_t *ent = a.entries + dsc.base + (uint64_t)t * dsc.cap;
-            // 16 entries in flight per thread as four 16-byte loads (buckets start on 128-byte boundaries and their
-            // capacity is a multiple of 32 entries, so a load never leaves the bucket; entries past `fill` are ignored)
-            const uint4 *ent4 = reinterpret_cast<const uint4 *>(ent);
-            for (uint32_t i0 = threadIdx.x * 4u; i0 < fill; i0 += blockDim.x * 4u * TEST_LOADS) {
+            // 16 entries in flight per thread as four 16-byte loads (buckets start on 128-byte boundaries, their fill marks
+            // are multiples of four entries: a load never straddles two buckets; k_tile_bin pads its runs with ENTRY_PAD)
+            uint32_t ci = 0;  // bucket of the thread's current position (positions only grow)
+            for (uint32_t v0 = threadIdx.x * 4u; v0 < total; v0 += blockDim.x * 4u * TEST_LOADS) {
                 uint4 en[TEST_LOADS];
+                uint32_t first[TEST_LOADS];
 #pragma unroll
                 for (uint32_t u = 0; u < TEST_LOADS; ++u) {
-                    const uint32_t i = i0 + u * blockDim.x * 4u;
-                    en[u] = i < fill ? ent4[i >> 2] : make_uint4(0u, 0u, 0u, 0u);
+                    const uint32_t v = v0 + u * blockDim.x * 4u;
+                    en[u] = make_uint4(ENTRY_PAD, ENTRY_PAD, ENTRY_PAD, ENTRY_PAD);
+                    first[u] = 0;
+                    if (v < total) {
+                        while (v >= s_pref[ci + 1]) ++ci;
+                        en[u] = *reinterpret_cast<const uint4 *>(a.entries + s_base[ci] + (v - s_pref[ci]));
+                        first[u] = s_first[ci];
+                    }
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < TEST_LOADS; ++u) {
-                    const uint32_t i = i0 + u * blockDim.x * 4u;
                     const uint32_t ev[4] = {en[u].x, en[u].y, en[u].z, en[u].w};
 #pragma unroll
                     for (uint32_t c = 0; c < 4; ++c) {
                         const uint32_t off = ev[c] & ((1u << TILE_LOG2) - 1u);
-                        if (i + c < fill && !((s_tile[off >> 5] >> (off & 31u)) & 1u)) atomicOr(&a.fail[dsc.first + (ev[c] >> TILE_LOG2)], 1u);
+                        if (ev[c] != ENTRY_PAD && !((s_tile[off >> 5] >> (off & 31u)) & 1u)) atomicOr(&a.fail[first[u] + (ev[c] >> TILE_LOG2)], 1u);
                     }
                 }
             }
+            if (n_mine < TEST_GROUP) break;  // (block-uniform) the leaf has no more chunks
         }
     }
 }
