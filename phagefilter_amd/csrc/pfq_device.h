@@ -18,7 +18,8 @@ struct HashParams {
     uint64_t nbits;       // d  (< 2^32)
     uint64_t bar_m;       // floor((2^64-1)/d)  Barrett multiplier
     uint64_t w64;         // 2^64 mod d
-    uint64_t a1, a2;      // (seed_s*K + k)*K : FxHasher state after write_usize(seed), write_usize(len)
+    uint64_t a1, a2;      // ((seed_s*K + k)*K)*K : FxHasher state after write_usize(seed), write_usize(len), times K once more
+                          // (the last round is (state + hb)*K = state*K + hb*K: hb*K is shared by the two seeded hashes)
 };
 
 constexpr uint32_t KMAX = 64;                        // supported k-mer length on the device path
@@ -162,9 +163,9 @@ __device__ __forceinline__ void kmer_hashes_at(const uint32_t *fw, const uint32_
     }
     const uint32_t *cw = use_rc ? rw : fw;
     uint32_t ca = use_rc ? ra : fa;
-    uint64_t hb = fx_hash_bytes_lds(cw, ca, k);
-    h1 = rotl64((hp.a1 + hb) * FX_K, 26);
-    h2 = rotl64((hp.a2 + hb) * FX_K, 26);
+    const uint64_t hbk = fx_hash_bytes_lds(cw, ca, k) * FX_K;
+    h1 = rotl64(hp.a1 + hbk, 26);
+    h2 = rotl64(hp.a2 + hbk, 26);
 }
 // k-mer at position q of the window staged by stage_window(…, cnt, …)
 __device__ __forceinline__ void kmer_hashes(const BlockLds &lds, uint32_t wave, uint32_t q, uint32_t cnt, bool valid,
@@ -197,6 +198,20 @@ __device__ __forceinline__ uint32_t mod_nbits(uint64_t r, const HashParams &hp) 
     return (uint32_t)rem;
 }
 
+// The same for d < 2^30: r - q*d < 3d < 2^32, so only the low words of r and q*d are needed and the two conditional
+// subtractions are 32-bit min() pairs.  (bar_m = floor((2^64-1)/d): floor(r/d) - 2 <= q <= floor(r/d).)
+__device__ __forceinline__ uint32_t mod_nbits30(uint64_t r, const HashParams &hp) {
+    const uint32_t q = (uint32_t)__umul64hi(r, hp.bar_m), d = (uint32_t)hp.nbits;
+    uint32_t rem = (uint32_t)r - q * d;
+    rem = min(rem, rem - d);
+    rem = min(rem, rem - d);
+    return rem;
+}
+
+__device__ __forceinline__ uint32_t mod_d(uint64_t r, const HashParams &hp) {  // (wave-uniform choice)
+    return hp.nbits < (1ull << 30) ? mod_nbits30(r, hp) : mod_nbits(r, hp);
+}
+
 // Iterator over the probe indices of one k-mer: i=0 -> h1 % d, i=1 -> h2 % d, i>=2 -> ((h1+i)*h2 mod 2^64) % d
 // (hash_iter.rs:13-27, bloom_filter.rs:319).  For i >= 3 the value advances by +h2 (mod 2^64), so the residue
 // advances by (h2 % d) and, when the 64-bit add wraps, by -(2^64 % d): no further wide multiplies.
@@ -206,10 +221,10 @@ struct ProbeIter {
     // after init: i0 = index 0, g = index 1, x = index 2
     __device__ __forceinline__ void init(uint64_t h1, uint64_t h2_, const HashParams &hp) {
         h2 = h2_;
-        i0 = mod_nbits(h1, hp);
-        g = mod_nbits(h2_, hp);
+        i0 = mod_d(h1, hp);
+        g = mod_d(h2_, hp);
         r = (h1 + 2) * h2_;
-        x = mod_nbits(r, hp);
+        x = mod_d(r, hp);
     }
     // index 3, 4, ... on successive calls
     __device__ __forceinline__ uint32_t step(const HashParams &hp) {
@@ -247,10 +262,10 @@ __device__ __forceinline__ void for_each_probe(ProbeIter &it, const HashParams &
 // Valid for d < 2^30 and num_hashes <= 35.
 __device__ __forceinline__ uint4 make_probe_record(uint64_t h1, uint64_t h2, const HashParams &hp) {
     uint4 rec;
-    rec.x = mod_nbits(h1, hp);
-    rec.y = mod_nbits(h2, hp);
+    rec.x = mod_nbits30(h1, hp);
+    rec.y = mod_nbits30(h2, hp);
     uint64_t r = (h1 + 2) * h2;
-    rec.z = mod_nbits(r, hp);
+    rec.z = mod_nbits30(r, hp);
     uint32_t cm = 0;
     for (uint32_t i = 3; i < hp.num_hashes; ++i) {
         uint64_t rn = r + h2;

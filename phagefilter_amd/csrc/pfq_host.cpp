@@ -283,8 +283,9 @@ int setup_hash_params(pfq_tree &t) {
     t.hp.bar_m = (~0ull) / t.nbits;
     t.hp.w64 = pow2_64_mod(t.nbits);
     // FxHasher after write_usize(seed) (hasher.rs:16-18) and the length prefix of <[u8] as Hash>::hash
-    t.hp.a1 = (t.seed1 * pfq::FX_K + t.kmer_size) * pfq::FX_K;
-    t.hp.a2 = (t.seed2 * pfq::FX_K + t.kmer_size) * pfq::FX_K;
+    // (times K once more: the kernels finish with rotl(a + hash_bytes * K), see pfq_device.h)
+    t.hp.a1 = (t.seed1 * pfq::FX_K + t.kmer_size) * pfq::FX_K * pfq::FX_K;
+    t.hp.a2 = (t.seed2 * pfq::FX_K + t.kmer_size) * pfq::FX_K * pfq::FX_K;
     return PFQ_OK;
 }
 

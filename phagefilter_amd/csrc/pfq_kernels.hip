@@ -18,9 +18,18 @@ namespace pfq {
 
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((31u << 11) | 20u) & 0xFu; }
 
+// Block barrier for data exchanged through LDS only.  __syncthreads() also waits for every outstanding global access of
+// the wave (s_waitcnt vmcnt(0)): in a software-pipelined loop that is a memory round trip per iteration.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 constexpr uint32_t SCREEN_ROUNDS = 2;  // row loads in flight per lane and probe in the theta=1 screen
 constexpr uint32_t SCREEN_KMERS = 4;   // k-mers the theta=1 screen looks at (rows of narrow trees would allow more per load)
 constexpr uint32_t PAIR_CHUNK = 32;    // slots a wave reserves at a time in the deferred-pair buffer
+constexpr uint32_t SCREEN_EXTRA = 8;   // k-mers the theta<1 screens look at beyond the maxmiss + 1 that can empty a frontier
 constexpr uint32_t NPLANES = 16;       // vertical-counter planes of the theta<1 screen (k-mers per read < 65536)
 
 struct ReadCtx {
@@ -71,7 +80,7 @@ __device__ __forceinline__ uint32_t screen_all(BlockLds &lds, uint32_t wave, con
     uint32_t cnt = (uint32_t)(rc.n < WIN_KMERS ? rc.n : WIN_KMERS);
     stage_window(lds, wave, rc.read, 0, cnt, a.hp.k);
     kmer_hashes(lds, wave, lane, cnt, lane < cnt, a.hp, h1, h2);
-    uint32_t i0 = mod_nbits(h1, a.hp), i1 = mod_nbits(h2, a.hp);
+    uint32_t i0 = mod_d(h1, a.hp), i1 = mod_d(h2, a.hp);
     uint32_t v0[SCREEN_ROUNDS], v1[SCREEN_ROUNDS];
 #pragma unroll
     for (uint32_t j = 0; j < SCREEN_ROUNDS; ++j) {
@@ -109,12 +118,13 @@ __device__ __forceinline__ uint32_t screen_counts_p(BlockLds &lds, uint32_t wave
 #pragma unroll
     for (uint32_t p = 0; p < P; ++p) c[p] = 0;
     uint32_t live = colmask;
-    for (uint64_t base = 0; base < rc.n; base += WIN_KMERS) {
-        uint32_t cnt = (uint32_t)((rc.n - base) < WIN_KMERS ? (rc.n - base) : WIN_KMERS);
+    const uint64_t n_scr = rc.n < rc.maxmiss + 1u + SCREEN_EXTRA ? rc.n : rc.maxmiss + 1u + SCREEN_EXTRA;  // (see dense_counts)
+    for (uint64_t base = 0; base < n_scr; base += WIN_KMERS) {
+        uint32_t cnt = (uint32_t)((n_scr - base) < WIN_KMERS ? (n_scr - base) : WIN_KMERS);
         stage_window(lds, wave, rc.read, base, cnt, a.hp.k);
         uint64_t h1, h2;
         kmer_hashes(lds, wave, lane, cnt, lane < cnt, a.hp, h1, h2);
-        uint32_t i0 = mod_nbits(h1, a.hp);
+        uint32_t i0 = mod_d(h1, a.hp);
         for (uint32_t t = 0; t < cnt; t += BATCH * slots) {
             uint32_t m[BATCH];
 #pragma unroll
@@ -218,7 +228,7 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
     const bool valid = t < nk;
     uint64_t h1, h2;
     kmer_hashes_at(fw, rw_, mb + t, mb + (W - t - k), valid, a.hp, h1, h2);
-    const uint32_t i0v = mod_nbits(h1, a.hp), i1v = mod_nbits(h2, a.hp);
+    const uint32_t i0v = mod_d(h1, a.hp), i1v = mod_d(h2, a.hp);
     const bool two = a.hp.num_hashes > 1;
     uint32_t survive = 0;
     irregular = 0;
@@ -315,6 +325,10 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
     // 300 bp at theta 0.5 with 8 planes)
     const bool regular = in_group && n64 >= 1 && n64 < (1ull << 31) && need >= 1 && need <= n64 && n64 - need < (1ull << P);
     const uint32_t n = regular ? (uint32_t)n64 : 0u, maxmiss = regular ? (uint32_t)(n64 - need) : 0u;
+    // The screen may stop after ANY prefix of the k-mers — a leaf is dropped only for misses it has seen, what is left
+    // is certified exactly — and the first maxmiss + 1 (+ a few for foreign leaves' lucky first bits) already empty the
+    // frontier of a read that hits nothing; a read that does hit would otherwise walk all its k-mers for nothing.
+    const uint32_t n_scr = n < maxmiss + 1u + SCREEN_EXTRA ? n : maxmiss + 1u + SCREEN_EXTRA;
     irregular = 0;
     {
         uint64_t b = ballot64(in_group && !regular && q == 0);
@@ -345,7 +359,7 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
     const uint32_t base = j * stride + WIN_PAD;
     bool alive = regular;  // my read still has a live leaf
     for (uint32_t pos = 0;; pos += lpr) {
-        const bool active = alive && pos < n;
+        const bool active = alive && pos < n_scr;
         if (ballot64(active) == 0) break;
         const uint32_t nk = active ? (n - pos < lpr ? n - pos : lpr) : 0u;
         const uint32_t W = nk ? nk + k - 1u : 0u;  // bytes staged for my read: <= lpr + KMAX - 1
@@ -374,7 +388,7 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
         kmer_hashes_at(fw, rw_, base + q, base + (W - q - k), valid, a.hp, h1, h2);
         // row indices of the wave go through LDS (live_out is free until the end): a lane fetches the eight of its
         // read with two 16-byte reads; k-mers that do not exist point at the all-ones row behind S (no miss)
-        live_out[lane] = valid ? mod_nbits(h1, a.hp) : a.ones_row;
+        live_out[lane] = valid ? mod_d(h1, a.hp) : a.ones_row;
         __builtin_amdgcn_wave_barrier();
         for (uint32_t t0 = 0; t0 < lpr; t0 += 8u) {
             const uint4 xa = *reinterpret_cast<const uint4 *>(live_out + (j << lpr_log2) + t0);
@@ -1090,7 +1104,7 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
                 if (ballot64(miss) && lane == 0) atomicOr(&a.fail[bcast_u32(idx_cur, j)], 1u);
             }
             if (threadIdx.x == 0) s_item[buf] = pend;
-            __syncthreads();
+            lds_barrier();  // (not __syncthreads: the next item's metadata load stays in flight)
             const uint64_t it_new = (uint64_t)s_item[buf] * stride + first;
             buf ^= 1u;
             it_cur = it_nxt;
@@ -1243,14 +1257,6 @@ __device__ __forceinline__ void flag_fallback(const TileArgs &a, uint32_t e) {
 }
 __device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, int src) {
     return ((unsigned long long)bcast_u32((uint32_t)(v >> 32), src) << 32) | bcast_u32((uint32_t)v, src);
-}
-// Block barrier for data exchanged through LDS only.  __syncthreads() also waits for every outstanding global access of
-// the wave (s_waitcnt vmcnt(0)): with bucket stores and next-round loads in flight that is a memory round trip per
-// round (measured: 3.4 of k_tile_bin's 10.3 ms).
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 template <uint32_t BIN_WAVES, uint32_t BIN_CAP>
 __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
@@ -1482,6 +1488,7 @@ constexpr uint32_t TEST_GROUP = 32;  // chunks of a leaf whose buckets are strea
 __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     extern __shared__ uint32_t s_tile[];  // 2^TILE_LOG2 bits
     __shared__ uint32_t s_pref[TEST_GROUP + 1], s_first[TEST_GROUP], s_misc[2];
+    __shared__ uint32_t s_failed[TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)];  // pairs of the group this block already reported
     __shared__ unsigned long long s_base[TEST_GROUP];
     const uint32_t tile_words = 1u << (TILE_LOG2 - 5);
     const uint64_t n_words32 = a.n_words * 2;
@@ -1496,6 +1503,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
             // The buckets (this tile's) of up to 32 chunks of the leaf, described once in LDS and then streamed as ONE
             // sequence of entries: a chunk's bucket alone (~20 k entries) would leave the block's 16 k-entry steps half idle.
             __syncthreads();  // the previous group / task is done with the LDS
+            for (uint32_t i = threadIdx.x; i < (TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)); i += blockDim.x) s_failed[i] = 0;
             if (threadIdx.x < 64) {
                 const uint32_t i = threadIdx.x, c = g0 + i;
                 ChunkDesc dsc{};
@@ -1543,16 +1551,18 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
             uint32_t ci = 0;  // bucket of the thread's current position (positions only grow)
             for (uint32_t v0 = threadIdx.x * 4u; v0 < total; v0 += blockDim.x * 4u * TEST_LOADS) {
                 uint4 en[TEST_LOADS];
-                uint32_t first[TEST_LOADS];
+                uint32_t first[TEST_LOADS], cidx[TEST_LOADS];
 #pragma unroll
                 for (uint32_t u = 0; u < TEST_LOADS; ++u) {
                     const uint32_t v = v0 + u * blockDim.x * 4u;
                     en[u] = make_uint4(ENTRY_PAD, ENTRY_PAD, ENTRY_PAD, ENTRY_PAD);
                     first[u] = 0;
+                    cidx[u] = 0;
                     if (v < total) {
                         while (v >= s_pref[ci + 1]) ++ci;
                         en[u] = *reinterpret_cast<const uint4 *>(a.entries + s_base[ci] + (v - s_pref[ci]));
                         first[u] = s_first[ci];
+                        cidx[u] = ci << CHUNK_PAIRS_LOG2;
                     }
                 }
 #pragma unroll
@@ -1561,7 +1571,12 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
 #pragma unroll
                     for (uint32_t c = 0; c < 4; ++c) {
                         const uint32_t off = ev[c] & ((1u << TILE_LOG2) - 1u);
-                        if (ev[c] != ENTRY_PAD && !((s_tile[off >> 5] >> (off & 31u)) & 1u)) atomicOr(&a.fail[first[u] + (ev[c] >> TILE_LOG2)], 1u);
+                        if (ev[c] != ENTRY_PAD && !((s_tile[off >> 5] >> (off & 31u)) & 1u)) {
+                            // a probed bit is 0: the pair fails.  A failing pair usually has hundreds of such probes (every
+                            // k-mer over a sequencing error): only the first one this block sees goes to memory.
+                            const uint32_t lp = ev[c] >> TILE_LOG2, fb = cidx[u] + lp;
+                            if (!(atomicOr(&s_failed[fb >> 5], 1u << (fb & 31u)) & (1u << (fb & 31u)))) atomicOr(&a.fail[first[u] + lp], 1u);
+                        }
                     }
                 }
             }

@@ -1,6 +1,6 @@
 run() { # name, env...
 name=$1; shift
-env PFQ_BENCH_NO_GATE=1 "$@" timeout -k 10 200 python bench.py --steps 5 --warmup 2 --cpu-seconds 0 > gpurun_out/exp_$name.json 2> gpurun_out/exp_$name.err
+env PFQ_BENCH_NO_GATE=1 "$@" timeout -k 10 200 python bench.py --steps 5 --warmup 2 --cpu-seconds 0 $BARGS > gpurun_out/exp_$name.json 2> gpurun_out/exp_$name.err
 python - <<PY
 import json
 try:

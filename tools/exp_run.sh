@@ -1,4 +1,6 @@
 source tools/exp2.sh
-run base PFQ_BIN_DEBUG=0
-run nostore PFQ_BIN_DEBUG=1
-run nobin PFQ_BIN_DEBUG=2
+BARGS="" run base
+BARGS="--threshold 0.3" run t03_clean
+BARGS="--threshold 0.3" run t03_err PFQ_BENCH_READ_ERRORS=0.01
+BARGS="--threshold 0.7" run t07_err PFQ_BENCH_READ_ERRORS=0.01
+BARGS="--threshold 1.0" run t10_err PFQ_BENCH_READ_ERRORS=0.01

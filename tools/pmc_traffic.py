@@ -34,11 +34,16 @@ def main() -> None:
     for f in files:
         for r in csv.DictReader(open(f)):
             rows[(int(r["Dispatch_Id"]), r["Kernel_Name"])][r["Counter_Name"]] = float(r["Counter_Value"])
-    # the dispatches of the LAST step: everything after the last k_classify launch group
+    # the dispatches of the LAST bucketed step: from the last k_classify<true, ...> (the deferring build) launch group up to
+    # the next k_classify of any kind (bench.py ends with a small parity query on the direct kernel)
     disp = sorted(rows.items())
-    last_start = max(i for i, ((_, k), _) in enumerate(disp) if "k_classify" in k and (i == 0 or "k_classify" not in disp[i - 1][0][1]))
+    is_cls = ["k_classify" in k for (_, k), _ in disp]
+    last_start = max(i for i, ((_, k), _) in enumerate(disp) if "k_classify<true" in k and (i == 0 or not is_cls[i - 1]))
+    end = last_start + 1
+    while end < len(disp) and not (is_cls[end] and not is_cls[end - 1]):
+        end += 1
     per = collections.defaultdict(int)
-    for (_, k), v in disp[last_start:]:
+    for (_, k), v in disp[last_start:end]:
         name = next((s for s, pat in SHORT if pat in k), None)
         if name is None:
             continue
