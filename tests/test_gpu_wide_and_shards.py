@@ -216,3 +216,99 @@ def test_replicas_on_one_device_allreduce_to_single_tree_counts(gpu):
         allreduce_counts([reps[0], reps[0]])
     for t in reps + [other]:
         t.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# related genomes: a read passes many leaves (what a phage database is)
+# ---------------------------------------------------------------------------------------------------------------
+def test_family_workload_parity_300k_reads(gpu):
+    """Families of 8 strains 0.2 % apart, 300 000 reads (>= 2^18: the bucketed path is chosen on its own): a positive read
+    is a candidate for ~8 leaves, so the first call outgrows the pair buffer (the overflow is certified inline) and the
+    following calls size it from what they saw.  Per-leaf counts and every per-read hit set equal the oracle's."""
+    import os
+    rng = np.random.default_rng(4242)
+    n_fam, fam, glen, k, h, nbits, n_reads = 8, 8, 4000, 21, 7, (1 << 20) + 7, 300000
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genomes_np = np.empty((n_fam * fam, glen), dtype=np.uint8)
+    for f in range(n_fam):
+        base = rng.choice(acgt, glen)
+        for j in range(fam):
+            g = base.copy()
+            mut = rng.random(glen) < 0.002
+            g[mut] = rng.choice(acgt, int(mut.sum()))
+            genomes_np[f * fam + j] = g
+    genomes = [g.tobytes() for g in genomes_np]
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    gt = gpu_tree(genomes, ids, k, nbits, h)
+    src = rng.integers(0, n_fam * fam, n_reads)
+    off0 = rng.integers(0, glen - 150, n_reads)
+    reads_np = genomes_np[src[:, None], off0[:, None] + np.arange(150)[None, :]]
+    neg = rng.random(n_reads) < 0.4
+    reads_np[neg] = rng.choice(acgt, (int(neg.sum()), 150))
+    err = rng.random(reads_np.shape) < 0.002                       # a few sequencing errors
+    reads_np[err] = rng.choice(acgt, int(err.sum()))
+    seq = np.concatenate([reads_np.reshape(-1), np.zeros(16, dtype=np.uint8)])
+    off = np.arange(n_reads + 1, dtype=np.uint64) * 150
+    for thr in (1.0, 0.6):
+        for v in range(ot.n_nodes):
+            ot.mapped_reads[v] = 0
+        ohits, _, _ = orc.query_batch_packed(ot, seq, off, thr, threads=min(32, os.cpu_count() or 8))
+        want = np.array(oracle_hits(ot, ohits), dtype=np.int64).reshape(-1, 2)
+        assert len(want) > 2 * n_reads                               # several leaves per positive read
+        for call in range(3):
+            gt.reset_counts()
+            gt.set_path(-1)
+            offs, leaves = gt.query_packed(seq, off, thr, want_hits=True)
+            st = gt.last_stats()
+            assert st.path == 1
+            assert gt.get_leaf_counts() == ot.leaf_counts(), (thr, call)
+            got = np.stack([np.repeat(np.arange(n_reads), np.diff(offs).astype(np.int64)), leaves.astype(np.int64)], 1)
+            assert np.array_equal(got, want), (thr, call)
+    gt.close()
+
+
+def test_harness_geometry_10010_genomes_on_one_gpu(gpu):
+    """The reference's own benchmark configuration names a 10 010-genome database (benchmarking/config.yaml:2) at the
+    harness's filter geometry (--false-pos-rate 0.00001 --largest-genome 500000: 11 981 322 bits, 17 hashes, k = 20;
+    bench/tools/phage_filter.py:84-85): 20 019 filters = 30 GB node-major + 5 column groups of the sliced matrix.  It must
+    open and classify on one GPU.  Size-independent properties (the oracle cannot hold it): every positive read hits its
+    source leaf, nothing else is hit beyond Bloom false positives, counts are additive and independent of the path."""
+    from hipbuf import DeviceBuffer, synchronize
+    from phagefilter_amd import _ffi
+    L = _ffi.lib()
+    n_g, glen, k, n_reads = 10010, 5000, 20, 1 << 20
+    nbits = orc.needed_bits(0.00001, 500000)
+    h = orc.optimal_num_hashes(nbits, 500000)
+    assert (nbits, h) == (11981322, 17)
+    ids = [f"G{i:05d}" for i in range(n_g)]
+    dg = DeviceBuffer(n_g * glen)
+    _ffi.check(L.pfq_synth_genomes_device(dg.ptr, n_g, glen, 0x5EED0000, None))
+    synchronize()
+    gt = BloomTree.build_balanced_device(dg.ptr, glen, n_g, ids, k, nbits, h, 0x0123456789ABCDEF, 0xFEDCBA9876543210,
+                                         0.00001, 500000)
+    info = gt.info()
+    assert (info.n_nodes, info.n_leaves, info.superset_verified) == (2 * n_g - 1, n_g, 1)
+    dr = DeviceBuffer(n_reads * 150 + 64)
+    _ffi.check(L.pfq_synth_reads_device(dr.ptr, 0, n_reads, 150, dg.ptr, glen, n_g, 0x5EED1234, None))
+    off = DeviceBuffer.from_numpy(np.arange(n_reads + 1, dtype=np.uint64) * 150)
+    synchronize()
+    pos, leaf = _read_plan(0x5EED1234, 0, n_reads, n_g)
+    expect = np.bincount(leaf[pos], minlength=n_g)
+
+    def counts(path, lo, hi, thr=1.0):
+        gt.reset_counts()
+        gt.set_path(path)
+        gt.query_device(dr.ptr + lo * 150, off.ptr, hi - lo, (hi - lo) * 150, thr, 0)
+        synchronize()
+        assert gt.last_stats().path == path
+        return np.array([c for _, c in gt.get_leaf_counts()], dtype=np.int64)
+
+    whole = counts(1, 0, n_reads)
+    assert (whole >= expect).all() and 0 <= int(whole.sum() - expect.sum()) <= 16
+    half = n_reads // 2
+    assert np.array_equal(counts(1, 0, half) + counts(1, half, n_reads), whole)
+    assert np.array_equal(counts(0, 0, 300001) + counts(0, 300001, n_reads), whole)
+    loose = counts(1, 0, n_reads, 0.3)                                # the harness's own threshold (config.yaml:4)
+    assert (loose >= whole).all() and int(loose.sum() - whole.sum()) <= n_reads // 1000
+    assert np.array_equal(counts(0, 0, n_reads, 0.3), loose)
+    gt.close()
