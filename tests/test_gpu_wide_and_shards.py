@@ -312,3 +312,65 @@ def test_harness_geometry_10010_genomes_on_one_gpu(gpu):
     assert (loose >= whole).all() and int(loose.sum() - whole.sum()) <= n_reads // 1000
     assert np.array_equal(counts(0, 0, n_reads, 0.3), loose)
     gt.close()
+
+
+@pytest.mark.parametrize("seed", [int(__import__("os").environ.get("PFQ_PARITY_SEED0", "0")) + i
+                                  for i in range(int(__import__("os").environ.get("PFQ_GUARD_SEEDS", "6")))])
+def test_randomized_parity_with_colliding_names(gpu, tmp_path, seed):
+    """Random trees in which some internal nodes alias another node's filter or lost bits (what colliding
+    Internal_Node_<u16> names do), read-length mixes from k to 20 kb, thresholds, both paths and forced
+    bucket-buffer sizes: guard pairs on the bucketed path against the oracle's full traversal."""
+    import os
+    rng = np.random.default_rng(7000 + seed)
+    n_genomes = int(rng.choice([5, 33, 130, 400, 2100]))
+    k = int(rng.choice([15, 21, 31]))
+    h = int(rng.choice([3, 7, 10]))
+    nbits = int(rng.choice([40009, 131072, 1 << 20]))
+    glen = int(rng.integers(max(k + 5, 80), 600))
+
+    def dna(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).astype(np.uint8))
+
+    base = [dna(glen) for _ in range(max(2, n_genomes // int(rng.choice([1, 4]))))]
+    genomes = []
+    for i in range(n_genomes):
+        g = bytearray(base[int(rng.integers(0, len(base)))])
+        for _ in range(int(rng.integers(0, 4))):
+            g[int(rng.integers(0, len(g)))] = ord("ACGT"[int(rng.integers(0, 4))])
+        genomes.append(bytes(g))
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    internal = [v for v in range(ot.n_nodes) if not ot.is_leaf(v)]
+    n_bad = max(1, len(internal) // int(rng.choice([3, 10, 40])))
+    for v in rng.choice(internal, size=min(n_bad, len(internal)), replace=False):
+        v = int(v)
+        if rng.random() < 0.5 and len(internal) > 1:
+            w = int(rng.choice(internal))
+            ot.bf_path[v], ot.filter_of[v] = ot.bf_path[w], ot.filter_of[w]
+        else:
+            ot.bits[ot.filter_of[v]][::int(rng.choice([2, 5, 50]))] = 0
+    d = str(tmp_path / "db")
+    fmt.write_db(ot, d)
+    reads = []
+    for _ in range(int(rng.integers(150, 400))):
+        src = genomes[int(rng.integers(0, n_genomes))] * int(rng.choice([1, 1, 4, 40]))
+        L = int(min(len(src), rng.choice([k, k + 1, 100, 150, 151, 300, 2000, 20000])))
+        o = int(rng.integers(0, len(src) - L + 1))
+        r = bytearray(src[o:o + L])
+        for _ in range(int(rng.choice([0, 0, 1, 4]))):
+            r[int(rng.integers(0, L))] = ord("ACGTN"[int(rng.integers(0, 5))])
+        reads.append(bytes(r) if rng.random() < 0.5 else orc.revcomp(bytes(r)))
+    reads += [dna(int(rng.integers(0, 300))) for _ in range(40)] + [b"", dna(k - 1)]
+    entries = int(rng.choice([0, 0, 30_000, 400_000]))
+    if entries:
+        os.environ["PFQ_TILE_ENTRIES"] = str(entries)
+    if seed % 2:
+        os.environ["PFQ_TILE_COUNTS"] = "1"
+    try:
+        gt = BloomTree.load(d)
+        for thr in (1.0, float(rng.choice([0.1, 0.5, 0.9])), float(rng.choice([0.0, 0.75, 0.999]))):
+            for path in (1, 0):
+                check_query(gt, ot, reads, thr, path=path)
+        gt.close()
+    finally:
+        os.environ.pop("PFQ_TILE_ENTRIES", None)
+        os.environ.pop("PFQ_TILE_COUNTS", None)
