@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--threshold", type=float, default=1.0)
     ap.add_argument("--path", type=int, default=-1, help="-1 auto, 0 direct kernel, 1 bucketed")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables the timing (not the parity check)")
+    ap.add_argument("--k", type=int, default=K, help="scenario runs only: k-mer size (the metric's workload is the default)")
+    ap.add_argument("--nbits", type=int, default=NBITS, help="scenario runs only: filter bits")
+    ap.add_argument("--hashes", type=int, default=NUM_HASHES, help="scenario runs only: hashes per k-mer")
     ap.add_argument("--subtree-depth", type=int, default=0, help="config 5: shards = nodes of this depth, one per rank (2^D == N)")
     ap.add_argument("--subtree-index", type=int, default=-1, help="N = 1 only: run this one shard of the depth-D frontier")
     return ap.parse_args()
@@ -85,7 +88,9 @@ def read_plan(np, seed, first, count, n_genomes):
 
 
 def main() -> None:
+    global K, NBITS, NUM_HASHES
     args = parse_args()
+    K, NBITS, NUM_HASHES = args.k, args.nbits, args.hashes
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         raise SystemExit(self_launch(args))
@@ -107,7 +112,15 @@ def main() -> None:
     backend = os.environ.get("PFQ_BENCH_BACKEND", "gloo" if same_gpu else "nccl")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # (PFQ_BENCH_FORCE_PG=1: a process group even for one rank, so that every RCCL call of the N > 1 path — init with a
+    # device id, barriers, the all-reduces and the all-gather — can be exercised on a one-GPU box)
+    use_pg = world > 1 or os.environ.get("PFQ_BENCH_FORCE_PG") == "1"
+    if use_pg:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
         else:
@@ -204,7 +217,7 @@ def main() -> None:
     counts = torch.zeros(max(n_local, 1), dtype=torch.int64, device=dev)
 
     def barrier() -> None:
-        if world > 1:
+        if use_pg:
             if backend == "nccl":
                 dist.barrier(device_ids=[dev_index])
             else:
@@ -231,7 +244,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     per_rank_s = [t_local]
-    if world > 1:
+    if use_pg:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -250,7 +263,7 @@ def main() -> None:
     # ---- checks on everything that was timed (all ranks): the reduction is the sum of the ranks' counters, every positive
     # read hit its source leaf, and what else was hit stays within the Bloom false-positive rate
     local_sum = torch.tensor([int(local_counts.sum().item())], dtype=torch.int64, device=dev)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(local_sum, op=dist.ReduceOp.SUM)
     problems = []
     if int(local_sum.item()) != total_hits:
@@ -335,8 +348,8 @@ def main() -> None:
                          "kernel": "whole step: " + " + ".join(k for k, v in kern.items() if v > 0),
                          "avg_launch_ms": kernels_ms, "algorithmic_bytes_per_launch": int(st.algorithmic_bytes),
                          "units_per_launch": B, "algorithmic_bytes_per_unit": int(st.algorithmic_bytes) / B},
-            "rccl_ranks": dist.get_world_size() if (world > 1 and backend == "nccl") else 0,
-            "collective_backend": backend if world > 1 else None, "allreduce_ms": allreduce_ms,
+            "rccl_ranks": dist.get_world_size() if (use_pg and backend == "nccl") else 0,
+            "collective_backend": backend if use_pg else None, "allreduce_ms": allreduce_ms,
             "per_rank_reads_per_s": [args.steps * B / s for s in per_rank_s],
             "query_path": "bucketed(screen + leaf-sorted certificates)" if st.path == 1 else "direct",
             "n_slices": int(st.n_slices), "tile_mode": int(st.tile_mode), "fallback_pairs": int(st.n_fallback_pairs),
@@ -370,7 +383,7 @@ def main() -> None:
         if world == 1 and args.cpu_seconds > 0 and "value" in check:
             result["cpu_baseline"] = {k: v for k, v in check.items() if k != "parity_sample"}
     bad = torch.tensor([len(problems)], dtype=torch.int64, device=dev)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(bad, op=dist.ReduceOp.SUM)
     if problems:
         print(f"[rank {rank}] bench.py: WRONG RESULTS, no bench line: " + "; ".join(problems), file=sys.stderr, flush=True)
@@ -380,7 +393,7 @@ def main() -> None:
     if rank == 0 and int(bad.item()) == 0:
         print(json.dumps(result), flush=True)
     tree.close()
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
     if int(bad.item()):
         raise SystemExit(1)

@@ -1468,12 +1468,18 @@ void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<8, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<16, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<16, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<16, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<16, 2048>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
     auto lds_of = [&](size_t cap) { return (2 * MAX_TILES + 64 + (size_t)a.n_tiles * (cap + 4)) * 4; };
     if (a.bin_shape == 3 && lds_of(256) <= 74 * 1024) {  // experiment: two 8-wave blocks per CU
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<8, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipLaunchKernelGGL((k_tile_bin<8, 256>), dim3(blocks), dim3(8 * 64), lds_of(256), st, a);
+    } else if (lds_of(2048) <= 148 * 1024 && a.bin_shape == 0) {  // few tiles (small filters): deeper bins, longer rounds
+        hipLaunchKernelGGL((k_tile_bin<16, 2048>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_of(2048), st, a);
+    } else if (lds_of(1024) <= 148 * 1024 && a.bin_shape == 0) {
+        hipLaunchKernelGGL((k_tile_bin<16, 1024>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_of(1024), st, a);
     } else if (lds_of(512) <= 148 * 1024 && a.bin_shape == 0) {
         hipLaunchKernelGGL((k_tile_bin<16, 512>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_of(512), st, a);
     } else if (lds_of(256) <= 148 * 1024 && a.bin_shape != 1) {

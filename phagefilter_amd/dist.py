@@ -21,7 +21,7 @@ def all_reduce_counts(counts):
     """Sum the per-leaf counters over all ranks in place (torch tensor, int64; the leaf order is identical on
     every rank because every rank holds the same tree).  No-op without an initialised process group."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
 

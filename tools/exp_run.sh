@@ -1,6 +1,3 @@
 source tools/exp2.sh
+BARGS="--leaves 10010 --genome-len 5000 --k 20 --nbits 11981322 --hashes 17 --read-len 100 --threshold 1.0" run harness10010_t10
 BARGS="" run base
-BARGS="--threshold 0.3" run t03_clean
-BARGS="--threshold 0.3" run t03_err PFQ_BENCH_READ_ERRORS=0.01
-BARGS="--threshold 0.7" run t07_err PFQ_BENCH_READ_ERRORS=0.01
-BARGS="--threshold 1.0" run t10_err PFQ_BENCH_READ_ERRORS=0.01
