@@ -167,7 +167,8 @@ int pfq_device_count(int *n);
  * own host thread.  This sums their per-leaf counters so that afterwards EVERY replica holds the job's totals
  * (mapped_reads of query.rs:143 as if one tree had seen all reads): replicas that share a device are added on that device,
  * then ONE ncclAllReduce(sum, uint64, n_leaves) over RCCL / xGMI runs across the distinct devices (8 KiB at 1024 leaves).
- * Waits for the replicas' queued work.  librccl is loaded when this is first called with more than one replica. */
+ * Waits for the replicas' queued work.  librccl is loaded when this first meets replicas on more than one device
+ * (PFQ_RCCL_ALWAYS=1: a one-rank communicator even then, for exercising the path on a one-GPU box). */
 int pfq_trees_allreduce_counts(pfq_tree *const *trees, uint32_t n_trees);
 /* Number of RCCL ranks the last pfq_trees_allreduce_counts on this thread used (0: no communicator was needed). */
 uint32_t pfq_last_allreduce_ranks(void);

@@ -815,6 +815,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         ta.n_words = t.n_words;
                         ta.recs = recs;
                         ta.meta = t.d_meta.p;
+                        ta.col_row = t.d_col_row.p;
                         ta.bucket_off = off;
                         ta.sub_log2 = sub_log2;
                         ta.n_leaves = (uint32_t)nc;
@@ -1772,7 +1773,11 @@ int pfq_trees_allreduce_counts(pfq_tree *const *trees, uint32_t n_trees) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
-    // (2) one all-reduce (sum, u64[n_leaves]) over RCCL across the devices, in place in each device's first replica
+    // (2) one all-reduce (sum, u64[n_leaves]) over RCCL across the devices, in place in each device's first replica.
+    // Replicas that all share one device need no communicator (loading librccl and ncclCommInitAll cost seconds);
+    // PFQ_RCCL_ALWAYS=1 makes a one-rank communicator anyway, so that the RCCL path can be exercised on a one-GPU box.
+    const char *always = getenv("PFQ_RCCL_ALWAYS");
+    if (by_dev.size() > 1 || (always && atoi(always) != 0)) {
     Rccl &r = rccl();
     if (!r.error.empty()) return fail(PFQ_ERR_DEVICE, r.error);
     std::vector<int> devs;
@@ -1798,6 +1803,7 @@ int pfq_trees_allreduce_counts(pfq_tree *const *trees, uint32_t n_trees) {
     if (rc != ncclSuccess) return fail(PFQ_ERR_DEVICE, std::string("ncclAllReduce: ") + r.GetErrorString(rc));
     if (he != hipSuccess) return fail(PFQ_ERR_DEVICE, std::string("all-reduce of the leaf counters: ") + hipGetErrorString(he));
     g_last_ranks = (uint32_t)devs.size();
+    }
     // (3) the totals go back to the other replicas of each device
     for (auto &kv : by_dev) {
         HIP_TRY(hipSetDevice(kv.first));

@@ -150,6 +150,7 @@ struct TileArgs {
     uint64_t n_words;
     const uint4 *recs;
     const uint4 *meta;           // per sorted pair (read offset lo, hi, length, row)
+    const uint32_t *col_row;     // column -> filter row
     const uint32_t *bucket_off;  // [(n_leaves << sub_log2) + 1]
     uint32_t sub_log2, n_leaves, n_tiles;   // n_leaves: buckets = leaf + guard columns
     uint32_t bin_shape;          // 0 auto, 1 force the 8 x 128 build of k_tile_bin, 2 force 16 x 256

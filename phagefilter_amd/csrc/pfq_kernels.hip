@@ -1491,103 +1491,136 @@ void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
 
 constexpr uint32_t TEST_LOADS = 4;   // 16-byte entry loads in flight per thread (8 measured slower: 6.1 vs 5.9 ms)
 constexpr uint32_t TEST_GROUP = 32;  // chunks of a leaf whose buckets are streamed as one sequence
+// A task = (column, tile): the block loads that 128 KiB tile of the column's filter into LDS and tests every probe binned
+// for it.  The tasks are software-pipelined: while task i's entries stream, the tile of task i + 1 is already on its way
+// into registers and its bucket descriptors into the other half of the descriptor arrays (a tile takes >= 5 us at the
+// per-CU load rate; trees with few pairs per leaf — subtree shards, thousands of leaves — spend most of a task there).
 __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     extern __shared__ uint32_t s_tile[];  // 2^TILE_LOG2 bits
-    __shared__ uint32_t s_pref[TEST_GROUP + 1], s_first[TEST_GROUP], s_misc[2];
+    __shared__ uint32_t s_pref[2][TEST_GROUP + 1], s_first[2][TEST_GROUP], s_misc[2][2];
     __shared__ uint32_t s_failed[TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)];  // pairs of the group this block already reported
-    __shared__ unsigned long long s_base[TEST_GROUP];
+    __shared__ unsigned long long s_base[2][TEST_GROUP];
     const uint32_t tile_words = 1u << (TILE_LOG2 - 5);
     const uint64_t n_words32 = a.n_words * 2;
     const uint64_t n_tasks = (uint64_t)a.n_leaves * a.n_tiles;
     const uint32_t n_chunks = *a.n_chunks < a.max_chunks ? *a.n_chunks : a.max_chunks;
-    for (uint64_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
-        const uint32_t leaf = (uint32_t)(task / a.n_tiles), t = (uint32_t)(task % a.n_tiles);
-        const uint32_t ch0 = a.leaf_chunk0[leaf];
-        if (ch0 == 0xffffffffu) continue;  // no pairs for this leaf
-        bool loaded = false;  // the tile is loaded when the first chunk of this pass is met (block-uniform)
-        for (uint32_t g0 = ch0;; g0 += TEST_GROUP) {
-            // The buckets (this tile's) of up to 32 chunks of the leaf, described once in LDS and then streamed as ONE
-            // sequence of entries: a chunk's bucket alone (~20 k entries) would leave the block's 16 k-entry steps half idle.
-            __syncthreads();  // the previous group / task is done with the LDS
-            for (uint32_t i = threadIdx.x; i < (TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)); i += blockDim.x) s_failed[i] = 0;
-            if (threadIdx.x < 64) {
-                const uint32_t i = threadIdx.x, c = g0 + i;
-                ChunkDesc dsc{};
-                const bool mine = i < TEST_GROUP && c < n_chunks && (dsc = a.chunks[c], dsc.leaf == leaf);
-                const bool usable = mine && dsc.cap != 0 && dsc.pass == a.pass;
-                uint32_t fill = usable ? a.gfill[(uint64_t)c * a.n_tiles + t] : 0u;
-                if (fill > dsc.cap) fill = dsc.cap;
-                uint32_t incl = fill;
-                for (uint32_t sft = 1; sft < TEST_GROUP; sft <<= 1) {
-                    const uint32_t o = (uint32_t)__shfl_up((int)incl, (int)sft);
-                    if (i >= sft) incl += o;
-                }
-                if (i < TEST_GROUP) {
-                    s_pref[i + 1] = incl;
-                    s_first[i] = dsc.first;
-                    s_base[i] = dsc.base + (uint64_t)t * dsc.cap;
-                }
-                const uint64_t um = ballot64(usable), mm = ballot64(mine);
-                if (i == 0) {
-                    s_pref[0] = 0;
-                    s_misc[0] = (uint32_t)__popcll(mm);                                                    // chunks of the leaf in this group
-                    s_misc[1] = um ? bcast_u32(dsc.row, __ffsll((unsigned long long)um) - 1) : 0xffffffffu;  // the leaf's filter row
-                }
-            }
-            __syncthreads();
-            const uint32_t n_mine = s_misc[0], row = s_misc[1], total = s_pref[TEST_GROUP];
-            if (total && !loaded) {
-                loaded = true;
-                // the leaf's tile: words [t * tile_words, ...) of its filter row (zero beyond the filter's end); filter rows
-                // are only 8-byte aligned: 8-byte loads, all sixteen of a thread in flight
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)row * a.n_words);
-                const uint64_t w0 = (uint64_t)t * tile_words;
-                uint2 v[16];
-#pragma unroll
-                for (uint32_t u = 0; u < 16; ++u) {
-                    const uint32_t i = threadIdx.x * 2 + u * 2048u;
-                    v[u] = (w0 + i + 1 < n_words32) ? *reinterpret_cast<const uint2 *>(src + w0 + i) : make_uint2(0, 0);
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < 16; ++u) *reinterpret_cast<uint2 *>(s_tile + threadIdx.x * 2 + u * 2048u) = v[u];
-                __syncthreads();
-            }
-            // 16 entries in flight per thread as four 16-byte loads (buckets start on 128-byte boundaries, their fill marks
-            // are multiples of four entries: a load never straddles two buckets; k_tile_bin pads its runs with ENTRY_PAD)
-            uint32_t ci = 0;  // bucket of the thread's current position (positions only grow)
-            for (uint32_t v0 = threadIdx.x * 4u; v0 < total; v0 += blockDim.x * 4u * TEST_LOADS) {
-                uint4 en[TEST_LOADS];
-                uint32_t first[TEST_LOADS], cidx[TEST_LOADS];
-#pragma unroll
-                for (uint32_t u = 0; u < TEST_LOADS; ++u) {
-                    const uint32_t v = v0 + u * blockDim.x * 4u;
-                    en[u] = make_uint4(ENTRY_PAD, ENTRY_PAD, ENTRY_PAD, ENTRY_PAD);
-                    first[u] = 0;
-                    cidx[u] = 0;
-                    if (v < total) {
-                        while (v >= s_pref[ci + 1]) ++ci;
-                        en[u] = *reinterpret_cast<const uint4 *>(a.entries + s_base[ci] + (v - s_pref[ci]));
-                        first[u] = s_first[ci];
-                        cidx[u] = ci << CHUNK_PAIRS_LOG2;
-                    }
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < TEST_LOADS; ++u) {
-                    const uint32_t ev[4] = {en[u].x, en[u].y, en[u].z, en[u].w};
-#pragma unroll
-                    for (uint32_t c = 0; c < 4; ++c) {
-                        const uint32_t off = ev[c] & ((1u << TILE_LOG2) - 1u);
-                        if (ev[c] != ENTRY_PAD && !((s_tile[off >> 5] >> (off & 31u)) & 1u)) {
-                            // a probed bit is 0: the pair fails.  A failing pair usually has hundreds of such probes (every
-                            // k-mer over a sequencing error): only the first one this block sees goes to memory.
-                            const uint32_t lp = ev[c] >> TILE_LOG2, fb = cidx[u] + lp;
-                            if (!(atomicOr(&s_failed[fb >> 5], 1u << (fb & 31u)) & (1u << (fb & 31u)))) atomicOr(&a.fail[first[u] + lp], 1u);
-                        }
-                    }
-                }
-            }
-            if (n_mine < TEST_GROUP) break;  // (block-uniform) the leaf has no more chunks
+    // next task of this block at or after `task` whose column has pairs at all (block-uniform)
+    auto valid_task = [&](uint64_t task) {
+        while (task < n_tasks && a.leaf_chunk0[(uint32_t)(task / a.n_tiles)] == 0xffffffffu) task += gridDim.x;
+        return task;
+    };
+    // The buckets (this tile's) of up to 32 chunks of the column starting at chunk g0, described in LDS: they are streamed
+    // as ONE sequence of entries (a chunk's bucket alone, ~20 k entries, would leave the block's 16 k-entry steps half idle).
+    auto describe = [&](uint32_t buf, uint32_t leaf, uint32_t t, uint32_t g0) {  // threads 0..63
+        const uint32_t i = threadIdx.x, c = g0 + i;
+        ChunkDesc dsc{};
+        const bool mine = i < TEST_GROUP && c < n_chunks && (dsc = a.chunks[c], dsc.leaf == leaf);
+        const bool usable = mine && dsc.cap != 0 && dsc.pass == a.pass;
+        uint32_t fill = usable ? a.gfill[(uint64_t)c * a.n_tiles + t] : 0u;
+        if (fill > dsc.cap) fill = dsc.cap;
+        uint32_t incl = fill;
+        for (uint32_t sft = 1; sft < TEST_GROUP; sft <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, (int)sft);
+            if (i >= sft) incl += o;
         }
+        if (i < TEST_GROUP) {
+            s_pref[buf][i + 1] = incl;
+            s_first[buf][i] = dsc.first;
+            s_base[buf][i] = dsc.base + (uint64_t)t * dsc.cap;
+        }
+        const uint64_t mm = ballot64(mine);
+        if (i == 0) {
+            s_pref[buf][0] = 0;
+            s_misc[buf][0] = (uint32_t)__popcll(mm);  // chunks of the column in this group
+        }
+    };
+    // the column's tile: words [t * tile_words, ...) of its filter row (zero beyond the filter's end); filter rows are only
+    // 8-byte aligned: 8-byte loads, all sixteen of a thread in flight
+    auto tile_loads = [&](uint32_t leaf, uint32_t t, uint2 (&v)[16]) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)a.col_row[leaf] * a.n_words);
+        const uint64_t w0 = (uint64_t)t * tile_words;
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u) {
+            const uint32_t i = threadIdx.x * 2 + u * 2048u;
+            v[u] = (w0 + i + 1 < n_words32) ? *reinterpret_cast<const uint2 *>(src + w0 + i) : make_uint2(0, 0);
+        }
+    };
+    auto tile_store = [&](const uint2 (&v)[16]) {
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u) *reinterpret_cast<uint2 *>(s_tile + threadIdx.x * 2 + u * 2048u) = v[u];
+        for (uint32_t i = threadIdx.x; i < (TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)); i += blockDim.x) s_failed[i] = 0;
+    };
+    // 16 entries in flight per thread as four 16-byte loads (buckets start on 128-byte boundaries, their fill marks are
+    // multiples of four entries: a load never straddles two buckets; k_tile_bin pads its runs with ENTRY_PAD)
+    auto stream = [&](uint32_t buf) {
+        const uint32_t total = s_pref[buf][TEST_GROUP];
+        uint32_t ci = 0;  // bucket of the thread's current position (positions only grow)
+        for (uint32_t v0 = threadIdx.x * 4u; v0 < total; v0 += blockDim.x * 4u * TEST_LOADS) {
+            uint4 en[TEST_LOADS];
+            uint32_t first[TEST_LOADS], cidx[TEST_LOADS];
+#pragma unroll
+            for (uint32_t u = 0; u < TEST_LOADS; ++u) {
+                const uint32_t v = v0 + u * blockDim.x * 4u;
+                en[u] = make_uint4(ENTRY_PAD, ENTRY_PAD, ENTRY_PAD, ENTRY_PAD);
+                first[u] = 0;
+                cidx[u] = 0;
+                if (v < total) {
+                    while (v >= s_pref[buf][ci + 1]) ++ci;
+                    en[u] = *reinterpret_cast<const uint4 *>(a.entries + s_base[buf][ci] + (v - s_pref[buf][ci]));
+                    first[u] = s_first[buf][ci];
+                    cidx[u] = ci << CHUNK_PAIRS_LOG2;
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < TEST_LOADS; ++u) {
+                const uint32_t ev[4] = {en[u].x, en[u].y, en[u].z, en[u].w};
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c) {
+                    const uint32_t off = ev[c] & ((1u << TILE_LOG2) - 1u);
+                    if (ev[c] != ENTRY_PAD && !((s_tile[off >> 5] >> (off & 31u)) & 1u)) {
+                        // a probed bit is 0: the pair fails.  A failing pair usually has hundreds of such probes (every
+                        // k-mer over a sequencing error): only the first one this block sees goes to memory.
+                        const uint32_t lp = ev[c] >> TILE_LOG2, fb = cidx[u] + lp;
+                        if (!(atomicOr(&s_failed[fb >> 5], 1u << (fb & 31u)) & (1u << (fb & 31u)))) atomicOr(&a.fail[first[u] + lp], 1u);
+                    }
+                }
+            }
+        }
+    };
+
+    uint64_t task = valid_task(blockIdx.x);
+    if (task >= n_tasks) return;
+    uint32_t buf = 0;
+    {
+        const uint32_t leaf = (uint32_t)(task / a.n_tiles), t = (uint32_t)(task % a.n_tiles);
+        uint2 v[16];
+        tile_loads(leaf, t, v);
+        if (threadIdx.x < 64) describe(0, leaf, t, a.leaf_chunk0[leaf]);
+        tile_store(v);
+        __syncthreads();
+    }
+    while (task < n_tasks) {
+        const uint32_t leaf = (uint32_t)(task / a.n_tiles), t = (uint32_t)(task % a.n_tiles);
+        const uint64_t nxt = valid_task(task + gridDim.x);
+        const bool have_nxt = nxt < n_tasks;
+        const uint32_t nleaf = have_nxt ? (uint32_t)(nxt / a.n_tiles) : 0u, nt = have_nxt ? (uint32_t)(nxt % a.n_tiles) : 0u;
+        uint2 vn[16];
+        if (have_nxt) tile_loads(nleaf, nt, vn);  // in flight while this task's entries stream
+        if (have_nxt && threadIdx.x < 64) describe(buf ^ 1u, nleaf, nt, a.leaf_chunk0[nleaf]);
+        for (uint32_t g0 = a.leaf_chunk0[leaf];;) {
+            stream(buf);
+            if (s_misc[buf][0] < TEST_GROUP) break;  // (block-uniform) the column has no more chunks
+            g0 += TEST_GROUP;                         // (rare: more than 32 chunks for one column) the next 32, same tile
+            __syncthreads();
+            if (threadIdx.x < 64) describe(buf, leaf, t, g0);
+            for (uint32_t i = threadIdx.x; i < (TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)); i += blockDim.x) s_failed[i] = 0;
+            __syncthreads();
+        }
+        __syncthreads();  // everybody is done with this task's tile and descriptors; the next task's descriptors are written
+        if (have_nxt) tile_store(vn);
+        __syncthreads();
+        task = nxt;
+        buf ^= 1u;
     }
 }
 void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st) {

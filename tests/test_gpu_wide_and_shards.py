@@ -205,10 +205,22 @@ def test_replicas_on_one_device_allreduce_to_single_tree_counts(gpu):
     for rep, a, b in zip(reps, cuts, cuts[1:]):
         seq, off = pack_reads(reads[a:b])
         rep.query_packed(seq, off, 0.7)
-    ranks = allreduce_counts(reps)
-    assert ranks == 1                                             # three replicas, one device: a one-rank RCCL communicator
+    import os
+    os.environ["PFQ_RCCL_ALWAYS"] = "1"                           # one device needs no communicator: ask for a one-rank one
+    try:
+        ranks = allreduce_counts(reps)
+    finally:
+        del os.environ["PFQ_RCCL_ALWAYS"]
+    assert ranks == 1                                             # librccl loaded, ncclCommInitAll + ncclAllReduce ran
     for rep in reps:
         assert rep.get_leaf_counts() == want                      # every replica holds the job's totals
+    for rep, a, b in zip(reps, cuts, cuts[1:]):                   # again without RCCL (replicas of one device are added there)
+        rep.reset_counts()
+        seq, off = pack_reads(reads[a:b])
+        rep.query_packed(seq, off, 0.7)
+    assert allreduce_counts(reps) == 0
+    for rep in reps:
+        assert rep.get_leaf_counts() == want
     other = gpu_tree(genomes[:5], ids[:5], 21, 60013, 6)
     with pytest.raises(PfqError):
         allreduce_counts([reps[0], other])                        # not replicas of one database

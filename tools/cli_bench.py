@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--leaves", type=int, default=64)
     ap.add_argument("--threshold", default="1.0", help="-f of every query run")
     ap.add_argument("--block", default="100000", help="-b of every query run")
+    ap.add_argument("--devices", default="", help="comma-separated device lists to run as well, ';'-separated (e.g. '0,0' = two replicas on GPU 0)")
     a = ap.parse_args()
     import torch
     from phagefilter_amd import BloomTree, _ffi
@@ -108,6 +109,9 @@ def main():
         run("fastq counts-only", fq, a.reads, t)
     tmax = max(int(x) for x in a.threads.split(","))
     run("fastq pos+neg output", fq, a.reads, tmax, ("--pos-filter", "--neg-filter"))
+    for devs in [d for d in a.devices.split(";") if d]:
+        run(f"fastq counts-only --devices {devs}", fq, a.reads, tmax, ("--devices", devs))
+        run(f"fastq pos+neg output --devices {devs}", fq, a.reads, tmax, ("--devices", devs, "--pos-filter", "--neg-filter"))
     # gzip: a directory of 8 parts (streams inflate side by side), 1/4 of the reads
     gzdir = os.path.join(a.workdir, "gz")
     os.makedirs(gzdir)

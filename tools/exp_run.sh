@@ -1,3 +1,5 @@
 source tools/exp2.sh
-BARGS="--leaves 10010 --genome-len 5000 --k 20 --nbits 11981322 --hashes 17 --read-len 100 --threshold 1.0" run harness10010_t10
 BARGS="" run base
+BARGS="--leaves 4096" run leaves4096
+BARGS="--subtree-depth 3 --subtree-index 5 --leaves 16384" run config5_shard
+BARGS="" run fam8 PFQ_BENCH_FAMILY=8
