@@ -158,10 +158,12 @@ struct pfq_tree {
     DevBuf<uint32_t> d_owner, d_owner_sorted, d_gfail;  // trees with guard columns, bucketed path: leaf pair of every pair slot
     DevBuf<unsigned long long> d_counts;
     // ---- query scratch
-    DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit, [1] pair, [2] tile entries, [3] lo: chunks, hi: flagged pairs, [4] long reads, [5] miss words, [6] dirty pairs, [7] lo: open pairs after the tile passes (thresholds < 1)
+    DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit, [1] pair, [2] tile entries, [3] lo: chunks, hi: flagged pairs, [4] long reads, [5] miss words, [6] dirty pairs, [7] lo: open pairs after the tile passes (thresholds < 1), [8] guard pairs, [9] k-mer miss bytes handed out
     DevBuf<uint32_t> d_entries, d_pair_chunk, d_leaf_chunk0, d_flag_list;  // LDS-tile certificates
     DevBuf<pfq::ChunkDesc> d_chunks;
     DevBuf<unsigned int> d_gfill, d_binq;
+    DevBuf<uint8_t> d_kmiss;
+    DevBuf<uint32_t> d_round_k0, d_n_rounds, d_pair_kpos;  // thresholds < 1: LDS-tile passes with k-mer entries
     uint32_t last_tile_mode = 0, last_passes = 1;
     DevBuf<uint2> d_hit_pairs, d_pairs, d_sorted;
     DevBuf<uint32_t> d_bucket, d_fail;  // bucket: cnt[n], off[n+1], cur[n]
@@ -783,12 +785,12 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 if (!recs) { vthreads = 256; vblocks = 1024; v.chunk = 4; }  // re-hash fallback kernel: 4-wave blocks
                 // LDS-tile certificates: every probe binned by (leaf chunk, 128 KiB filter tile), tiles tested out of LDS;
                 // k_verify_rec then only sees the pairs that could not be binned
-                const uint32_t n_tiles = (uint32_t)((t.n_words * 64 + (1ull << pfq::TILE_LOG2) - 1) >> pfq::TILE_LOG2);
-                // Thresholds < 1: a tile pass tells the pairs with every k-mer contained (nothing to count) from the rest, which
-                // k_verify_rec then takes for their exact miss bits.  That pays when few pairs miss a k-mer (config 3, theta 0.3:
-                // 50 ms per step instead of 61 with none, 58 with 14 %, 65 with 36 %: break-even near a quarter); the share is the
-                // last call's (unknown: record kernel only).  Results do not depend on the choice.
-                bool tile_counts = t.dirty_frac < 0.2;
+                // (thresholds < 1: entries name k-mers, tiles are half the size — pfq::TILE_LOG2_COUNTS)
+                const uint32_t tile_log2 = counts_mode ? pfq::TILE_LOG2_COUNTS : pfq::TILE_LOG2;
+                const uint32_t n_tiles = (uint32_t)((t.n_words * 64 + (1ull << tile_log2) - 1) >> tile_log2);
+                // Thresholds < 1: the tile passes leave the k-mers that are not contained in per-chunk miss bitmaps; k_verify_rec
+                // only sees what could not be binned.  (PFQ_TILE_COUNTS=0: record kernel only.)  Results do not depend on the choice.
+                bool tile_counts = true;
                 if (kn.tile_counts >= 0) tile_counts = kn.tile_counts != 0;
                 bool tile_mode = recs && (!counts_mode || tile_counts) && n_tiles < pfq::MAX_TILES;
                 if (kn.tile >= 0) tile_mode = tile_mode && kn.tile != 0;
@@ -803,8 +805,15 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                                     max_chunks * n_tiles * 544ull;
                     if (want * 4 > tile_budget) want = tile_budget / 4;
                     if (kn.tile_entries >= 0) want = std::max<uint64_t>(1, (uint64_t)kn.tile_entries);  // tests: force passes
-                    if (!(soft_ensure(t.d_entries, want) && soft_ensure(t.d_pair_chunk, t.d_pairs.n) && soft_ensure(t.d_flag_list, t.d_pairs.n) &&
-                          soft_ensure(t.d_leaf_chunk0, nc + 1) && soft_ensure(t.d_chunks, max_chunks) && soft_ensure(t.d_gfill, max_chunks * n_tiles) && soft_ensure(t.d_binq, 256))) {
+                    // thresholds < 1: one miss byte per k-mer of every pair the recent calls make expect (chunks that find no room
+                    // take the fallback), the rounds' positions, the pairs' positions
+                    const uint64_t kmiss_cap = counts_mode ? std::min<uint64_t>((uint64_t)((double)total_bytes * std::max(1.0, 1.3 * t.pairs_per_read)) + 16 * max_chunks + 64, 0xfffffff0ull) & ~15ull : 0;
+                    bool ok = soft_ensure(t.d_entries, want) && soft_ensure(t.d_pair_chunk, t.d_pairs.n) && soft_ensure(t.d_flag_list, t.d_pairs.n) &&
+                              soft_ensure(t.d_leaf_chunk0, nc + 1) && soft_ensure(t.d_chunks, max_chunks) && soft_ensure(t.d_gfill, max_chunks * n_tiles) && soft_ensure(t.d_binq, 256);
+                    if (ok && counts_mode)
+                        ok = soft_ensure(t.d_kmiss, kmiss_cap) && soft_ensure(t.d_round_k0, max_chunks * pfq::MAX_ROUNDS) &&
+                             soft_ensure(t.d_n_rounds, max_chunks) && soft_ensure(t.d_pair_kpos, t.d_pairs.n);
+                    if (!ok) {
                         tile_mode = false;  // not enough HBM for the probe buckets: stay with the record kernel
                     } else {
                         HIP_TRY(hipMemsetAsync(t.d_gfill.p, 0, max_chunks * n_tiles * 4, st));
@@ -835,6 +844,16 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         ta.gfill = t.d_gfill.p;
                         ta.fail = t.d_fail.p;
                         ta.n_pairs_ptr = off + nb;
+                        if (counts_mode) {
+                            ta.counts = 1;
+                            ta.kmiss = t.d_kmiss.p;
+                            ta.kmiss_cap = kmiss_cap;
+                            ta.kmiss_used = t.d_cursors.p + 9;
+                            ta.round_k0 = t.d_round_k0.p;
+                            ta.n_rounds = t.d_n_rounds.p;
+                            ta.pair_kpos = t.d_pair_kpos.p;
+                            HIP_TRY(hipMemsetAsync(t.d_n_rounds.p, 0, max_chunks * 4, st));
+                        }
                         int bin_blocks = 512, test_blocks = 512;
                         if (kn.bin_blocks >= 0) bin_blocks = std::max(1, (int)kn.bin_blocks);
                         if (kn.test_blocks >= 0) test_blocks = std::max(1, (int)kn.test_blocks);
@@ -901,6 +920,13 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 f.hit_cursor = t.d_cursors.p;
                 f.stats = t.d_stats.p;
                 f.n_dirty = t.d_cursors.p + 6;
+                if (counts_mode && t.last_tile_mode) {  // miss bits of the binned pairs: in their chunks' bitmaps
+                    f.kmiss = t.d_kmiss.p;
+                    f.pair_kpos = t.d_pair_kpos.p;
+                    f.pair_chunk = t.d_pair_chunk.p;
+                    f.chunks = t.d_chunks.p;
+                    f.launched_passes = v.launched_passes;
+                }
                 f.owner_sorted = with_guards ? t.d_owner_sorted.p : nullptr;
                 f.gfail = with_guards ? t.d_gfail.p : nullptr;
                 t.hint_counts = counts_mode;

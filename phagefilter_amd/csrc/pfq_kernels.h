@@ -124,6 +124,13 @@ struct FinalizeArgs {
     unsigned long long *hit_cursor;
     unsigned long long *stats;
     unsigned long long *n_dirty;  // thresholds < 1: += pairs with at least one k-mer missing (sizes the next call's certificate stage)
+    // thresholds < 1 after LDS-tile passes with k-mer entries: a pair that was binned in a launched pass and never flagged
+    // has its miss bits in its chunk's bitmap (kmiss); every other pair in its own miss words (written by k_verify_rec)
+    const uint8_t *kmiss;         // nullptr: miss words only
+    const uint32_t *pair_kpos;
+    const uint32_t *pair_chunk;
+    const ChunkDesc *chunks;
+    uint32_t launched_passes;
 };
 
 // ---- LDS-tile certificates (bucketed path, records available) ------------------------------------------------------
@@ -134,6 +141,13 @@ constexpr uint32_t TILE_LOG2 = 20;                 // bits per tile = 128 KiB of
 constexpr uint32_t CHUNK_PAIRS_LOG2 = 10;          // pairs per chunk: local pair id and tile offset share one u32 entry; a chunk
                                                    // is the work item of k_tile_bin (one block bins it alone)
 constexpr uint32_t MAX_TILES = 256;                // filters up to 2^27 bits take this path
+// Thresholds < 1: the passes must tell WHICH k-mers are not contained, so an entry names a k-mer instead of a pair:
+// [round tag : 2][k-mer of the round : 11][offset in tile : 19] — k_tile_bin bins a chunk in rounds of <= 2^11 flattened
+// k-mers, the four entries of a 16-byte vector (runs are 16-byte aligned) carry the round's number in their tag bits, and
+// round_k0[chunk][round] turns (round, k-mer of the round) into the k-mer's position in the chunk's miss bitmap.
+constexpr uint32_t TILE_LOG2_COUNTS = 19;          // 64 KiB tiles (twice the tiles, 128-entry deeper bins than needed)
+constexpr uint32_t ROUND_KMERS_LOG2 = 11;          // flattened k-mers per round of k_tile_bin (= 2 windows x 16 waves)
+constexpr uint32_t MAX_ROUNDS = 256;               // rounds per chunk the tags can name; later pairs take the fallback
 struct ChunkDesc {
     uint32_t row;      // filter row of the leaf
     uint32_t first;    // first sorted pair
@@ -142,6 +156,8 @@ struct ChunkDesc {
     uint64_t base;     // first entry of tile 0's bucket
     uint32_t leaf;
     uint32_t pass;     // the probe buckets are reused: chunks are binned and tested pass after pass
+    uint32_t kbase;    // thresholds < 1: first byte of the chunk's k-mer miss array (byte = position of the k-mer in the chunk)
+    uint32_t kwords;   //                 its size in 16-byte units
 };
 struct TileArgs {
     uint32_t pass;               // k_tile_bin / k_tile_test: only the chunks of this pass
@@ -170,6 +186,14 @@ struct TileArgs {
     uint32_t *flag_list;         // [flag_cap] their sorted-pair indices
     uint32_t flag_cap;
     const uint32_t *n_pairs_ptr;
+    // thresholds < 1 (entries name k-mers, see TILE_LOG2_COUNTS)
+    uint32_t counts;             // 1: k-mer entries, 64 KiB tiles, miss bits; 0: pair entries, 128 KiB tiles, fail words
+    uint8_t *kmiss;              // k-mer miss bytes of all chunks (a byte, not a bit: set with plain stores from any XCD)
+    uint64_t kmiss_cap;          // its bytes, < 2^32 (chunks that find no room take the fallback)
+    unsigned long long *kmiss_used;  // bytes handed out by k_tile_assign (cleared before the passes)
+    uint32_t *round_k0;          // [max_chunks][MAX_ROUNDS] position (in the chunk) of the first k-mer of every round
+    uint32_t *n_rounds;          // [max_chunks]
+    uint32_t *pair_kpos;         // [sorted pair] position of the pair's first k-mer in its chunk
 };
 void launch_tile_plan(const TileArgs &a, hipStream_t st);
 void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st);

@@ -1162,6 +1162,9 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
             dsc.base = 0;
             dsc.leaf = c;
             dsc.pass = 0;
+            dsc.kbase = 0;   // (placed by k_tile_assign)
+            dsc.kwords = a.counts ? (uint32_t)((s_sum + 15) >> 4) : 0u;  // one miss byte per k-mer of the chunk, in 16-byte units
+            if (a.counts && s_sum >= (1ull << 31)) dsc.cap = 0;
             a.chunks[chunk] = dsc;
         }
         __syncthreads();
@@ -1177,6 +1180,25 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
 __global__ void __launch_bounds__(64) k_tile_assign(TileArgs a) {
     const uint32_t lane = lane_id();
     const uint32_t n_chunks = *a.n_chunks < a.max_chunks ? *a.n_chunks : a.max_chunks;
+    if (a.counts) {  // thresholds < 1: the chunks' k-mer miss bytes, packed in order; a chunk that finds no room takes the fallback
+        unsigned long long run = 0;  // wave-uniform
+        for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            const bool have = c < n_chunks && a.chunks[c].cap != 0;
+            const unsigned long long need = have ? (unsigned long long)a.chunks[c].kwords * 16u : 0u;
+            unsigned long long incl = need;
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const unsigned long long o = __shfl_up(incl, dd);
+                if ((int)lane >= dd) incl += o;
+            }
+            if (have) {
+                if (run + incl <= a.kmiss_cap) a.chunks[c].kbase = (uint32_t)(run + incl - need);
+                else a.chunks[c].cap = 0;
+            }
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) *a.kmiss_used = run < a.kmiss_cap ? run : a.kmiss_cap;  // (k_zero16 clears that much)
+    }
     unsigned long long total = 0;
     for (uint32_t c = lane; c < n_chunks; c += 64) total += (unsigned long long)a.chunks[c].cap * a.n_tiles;
     for (int dd = 32; dd > 0; dd >>= 1) total += __shfl_xor(total, dd);
@@ -1228,10 +1250,15 @@ __global__ void __launch_bounds__(64) k_tile_assign(TileArgs a) {
     }
     if (lane == 0) *a.entry_cursor = (unsigned long long)pass * a.entry_cap + off;
 }
+__global__ void __launch_bounds__(256) k_zero16(uint4 *p, const unsigned long long *n_bytes) {
+    const uint64_t n = (*n_bytes + 15) >> 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = make_uint4(0, 0, 0, 0);
+}
 void launch_tile_plan(const TileArgs &a, hipStream_t st) {
     if (!a.n_leaves) return;
     hipLaunchKernelGGL(k_tile_plan, dim3(a.n_leaves), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_tile_assign, dim3(1), dim3(64), 0, st, a);
+    if (a.counts) hipLaunchKernelGGL(k_zero16, dim3(2048), dim3(256), 0, st, reinterpret_cast<uint4 *>(a.kmiss), a.kmiss_used);
 }
 
 // k_tile_bin: a block takes whole chunks from a queue and bins every probe of the chunk's pairs by filter tile.
@@ -1258,8 +1285,13 @@ __device__ __forceinline__ void flag_fallback(const TileArgs &a, uint32_t e) {
 __device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, int src) {
     return ((unsigned long long)bcast_u32((uint32_t)(v >> 32), src) << 32) | bcast_u32((uint32_t)v, src);
 }
-template <uint32_t BIN_WAVES, uint32_t BIN_CAP>
+template <uint32_t BIN_WAVES, uint32_t BIN_CAP, bool COUNTS>
 __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
+    // COUNTS (thresholds < 1): an entry is [round tag:2][flattened k-mer of the round:11][offset in a 64 KiB tile:19]; the
+    // tags are ORed in at flush time (position in the 16-byte vector -> two bits of the round's number), runs are padded
+    // with copies of their last entry (testing a probe twice changes nothing), and per round the chunk position of its
+    // first k-mer goes to round_k0, per pair the position of its first k-mer to pair_kpos.
+    constexpr uint32_t TL = COUNTS ? TILE_LOG2_COUNTS : TILE_LOG2;
     constexpr uint32_t BIN_STRIDE = BIN_CAP + 4;  // rows stay 16-byte aligned; room for the padding of a full bin
     constexpr uint32_t WPI = 2;                    // windows per wave and iteration
     constexpr uint32_t DUMMY = MAX_TILES;          // counters MAX_TILES .. MAX_TILES + 63: where lanes without a probe count
@@ -1271,6 +1303,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
     const uint32_t n_chunks = *a.n_chunks < a.max_chunks ? *a.n_chunks : a.max_chunks;
     uint32_t KB = (uint32_t)(((uint64_t)(BIN_CAP - BIN_CAP / 4) * a.n_tiles) / nh);
     if (KB > WPI * BIN_WAVES * WIN_KMERS) KB = WPI * BIN_WAVES * WIN_KMERS;
+    if (COUNTS && KB > (1u << ROUND_KMERS_LOG2)) KB = 1u << ROUND_KMERS_LOG2;
     if (KB == 0) KB = 1;
     for (uint32_t t = threadIdx.x; t < MAX_TILES + 64; t += blockDim.x) cnt[t] = 0;
     while (true) {
@@ -1292,7 +1325,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
         // Lanes 0..31 of every wave hold the candidates p + lane (every wave computes the same); `incl` = inclusive prefix
         // sums of their k-mer counts, qb = record index of flattened k-mer 0 of the lane's pair.
         struct Round {
-            uint32_t p, P, K, incl;
+            uint32_t p, P, K, incl, start;  // start: flattened index of the first k-mer of the lane's pair
             unsigned long long koff, qb;
             bool partial;
         };
@@ -1309,6 +1342,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                 if (lane >= sft) incl += o;
             }
             r.incl = incl;
+            r.start = incl - n_l;
             r.P = (uint32_t)__popcll(ballot64(cand && incl <= KB));  // incl is monotone: a prefix of the candidates
             r.partial = r.P == 0 && p < dsc.n;  // the first pair alone exceeds the budget: the next KB k-mers of it
             if (r.partial) {
@@ -1342,7 +1376,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                     }
                 }
                 rec[u] = valid[u] ? a.recs[qb + f] : make_uint4(0, 0, 0, 0);  // (no k-mer: every index 0, see `put`)
-                local[u] = (r.p + j) << TILE_LOG2;
+                local[u] = (COUNTS ? f : r.p + j) << TL;
             }
         };
         // Software pipeline over the rounds: while round r is binned, the records of round r + 1 and the pair metadata of
@@ -1358,7 +1392,17 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
             const uint32_t p1 = cur.partial ? cur.p : cur.p + cur.P;
             m_nxt = load_meta(p1);
         }
+        uint32_t rho = 0, k0 = 0;  // COUNTS: number of this round; chunk position of its first k-mer
         while (cur.p < dsc.n) {
+            if (COUNTS) {
+                if (rho >= MAX_ROUNDS) {  // the tags cannot name more rounds: what is left of the chunk takes the fallback
+                    for (uint32_t i = cur.p + threadIdx.x; i < dsc.n; i += blockDim.x) flag_fallback(a, dsc.first + i);
+                    break;
+                }
+                if (threadIdx.x == 0) a.round_k0[(uint64_t)c * MAX_ROUNDS + rho] = k0;
+                // (a pair binned over several rounds keeps the position of its first piece; the pieces are contiguous)
+                if (wave == 0 && lane < cur.P && (lane > 0 || cur.koff == 0)) a.pair_kpos[dsc.first + cur.p + lane] = k0 + (cur.partial ? 0u : cur.start);
+            }
             const uint32_t p1 = cur.partial ? cur.p : cur.p + cur.P;
             const Round nxt = compose(p1, cur.partial ? cur.koff + KB : 0ull, m_nxt);
             uint4 rec_n[WPI];
@@ -1380,12 +1424,12 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                 auto put = [&](const uint32_t (&ix)[WPI]) {
                     uint32_t tile[WPI], slot[WPI];
 #pragma unroll
-                    for (uint32_t u = 0; u < WPI; ++u) tile[u] = ix[u] >> TILE_LOG2;
+                    for (uint32_t u = 0; u < WPI; ++u) tile[u] = ix[u] >> TL;
 #pragma unroll
                     for (uint32_t u = 0; u < WPI; ++u) slot[u] = atomicAdd(&cnt[cbase[u] + tile[u]], 1u);
 #pragma unroll
                     for (uint32_t u = 0; u < WPI; ++u)
-                        if (valid[u]) bins[tile[u] * BIN_STRIDE + min(slot[u], BIN_CAP - 1u)] = local[u] | (ix[u] & ((1u << TILE_LOG2) - 1u));
+                        if (valid[u]) bins[tile[u] * BIN_STRIDE + min(slot[u], BIN_CAP - 1u)] = local[u] | (ix[u] & ((1u << TL) - 1u));
                 };
                 uint32_t ix[WPI];
 #pragma unroll
@@ -1410,7 +1454,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
             lds_barrier();  // every probe of the round is in its bin
             // (the next round's records are taken over BEFORE the bucket stores are issued: waiting for them afterwards would
             // also wait for every store, which are younger in the same counter)
-            const uint32_t flush_p = cur.p, flush_P = cur.P;
+            const uint32_t flush_p = cur.p, flush_P = cur.P, flush_K = cur.K;
             cur = nxt;
 #pragma unroll
             for (uint32_t u = 0; u < WPI; ++u) {
@@ -1427,7 +1471,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                 const uint32_t cn = have ? cnt[t] : 0u, pos = have ? fillp[t] : 0u;
                 const uint32_t cc = cn < BIN_CAP ? cn : BIN_CAP, c4 = (cc + 3u) & ~3u;
                 uint32_t *row = bins + t * BIN_STRIDE;
-                if (sl < c4 - cc) row[cc + sl] = ENTRY_PAD;
+                if (sl < c4 - cc) row[cc + sl] = COUNTS ? row[cc - 1u] : ENTRY_PAD;  // (c4 > cc only when cc >= 1)
                 __builtin_amdgcn_wave_barrier();
                 // what fits is written (k_tile_test reads min(fill, cap) entries: every slot below cap must hold an entry
                 // or padding); the pairs whose probes are dropped — bucket full — take the fallback
@@ -1443,12 +1487,22 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
 #pragma unroll
                     for (uint32_t u = 0; u < FB; ++u)  // (keeps the compiler from sinking every read next to its store)
                         asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+                    if (COUNTS) {  // the round's number, two bits per entry of a vector
+#pragma unroll
+                        for (uint32_t u = 0; u < FB; ++u) {
+                            v[u].x |= (rho & 3u) << 30;
+                            v[u].y |= ((rho >> 2) & 3u) << 30;
+                            v[u].z |= ((rho >> 4) & 3u) << 30;
+                            v[u].w |= ((rho >> 6) & 3u) << 30;
+                        }
+                    }
 #pragma unroll
                     for (uint32_t u = 0; u < FB; ++u)
                         if (i0 + u * 64u < wr_eff) *reinterpret_cast<uint4 *>(dst + i0 + u * 64u) = v[u];
                 }
-                for (uint32_t i = wr + sl; i < cc; i += 16) flag_fallback(a, dsc.first + (row[i] >> TILE_LOG2));
-                if (cn > BIN_CAP) {  // the LDS bin overflowed: whose probes were lost is unknown
+                if (!COUNTS)
+                    for (uint32_t i = wr + sl; i < cc; i += 16) flag_fallback(a, dsc.first + (row[i] >> TL));
+                if (cn > BIN_CAP || (COUNTS && wr < cc)) {  // the LDS bin (or, with k-mer entries, the bucket) overflowed: whose probes were lost is unknown
                     for (uint32_t i = sl; i < flush_P; i += 16) flag_fallback(a, dsc.first + flush_p + i);
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1458,49 +1512,62 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                 }
             }
             lds_barrier();  // bins and counters are free again
+            k0 += flush_K;
+            ++rho;
         }
+        if (COUNTS && threadIdx.x == 0) a.n_rounds[c] = rho;
         for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) a.gfill[(uint64_t)c * a.n_tiles + t] = fillp[t];
     }
 }
-void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
-    static bool attr_set = false;
+template <uint32_t W, uint32_t CAP>
+static void launch_tile_bin_shape(const TileArgs &a, int blocks, size_t lds, hipStream_t st) {
+    static bool attr_set = false;  // (per instantiation)
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<8, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<16, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<16, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<16, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<16, 2048>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
+    if (a.counts) hipLaunchKernelGGL((k_tile_bin<W, CAP, true>), dim3(blocks), dim3(W * 64), lds, st, a);
+    else hipLaunchKernelGGL((k_tile_bin<W, CAP, false>), dim3(blocks), dim3(W * 64), lds, st, a);
+}
+void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
     auto lds_of = [&](size_t cap) { return (2 * MAX_TILES + 64 + (size_t)a.n_tiles * (cap + 4)) * 4; };
     if (a.bin_shape == 3 && lds_of(256) <= 74 * 1024) {  // experiment: two 8-wave blocks per CU
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<8, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipLaunchKernelGGL((k_tile_bin<8, 256>), dim3(blocks), dim3(8 * 64), lds_of(256), st, a);
+        launch_tile_bin_shape<8, 256>(a, blocks, lds_of(256), st);
     } else if (lds_of(2048) <= 148 * 1024 && a.bin_shape == 0) {  // few tiles (small filters): deeper bins, longer rounds
-        hipLaunchKernelGGL((k_tile_bin<16, 2048>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_of(2048), st, a);
+        launch_tile_bin_shape<16, 2048>(a, (blocks + 1) / 2, lds_of(2048), st);
     } else if (lds_of(1024) <= 148 * 1024 && a.bin_shape == 0) {
-        hipLaunchKernelGGL((k_tile_bin<16, 1024>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_of(1024), st, a);
+        launch_tile_bin_shape<16, 1024>(a, (blocks + 1) / 2, lds_of(1024), st);
     } else if (lds_of(512) <= 148 * 1024 && a.bin_shape == 0) {
-        hipLaunchKernelGGL((k_tile_bin<16, 512>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_of(512), st, a);
+        launch_tile_bin_shape<16, 512>(a, (blocks + 1) / 2, lds_of(512), st);
     } else if (lds_of(256) <= 148 * 1024 && a.bin_shape != 1) {
-        hipLaunchKernelGGL((k_tile_bin<16, 256>), dim3((blocks + 1) / 2), dim3(16 * 64), lds_of(256), st, a);
+        launch_tile_bin_shape<16, 256>(a, (blocks + 1) / 2, lds_of(256), st);
     } else {
-        hipLaunchKernelGGL((k_tile_bin<8, 128>), dim3(blocks), dim3(8 * 64), lds_of(128), st, a);
+        launch_tile_bin_shape<8, 128>(a, blocks, lds_of(128), st);
     }
 }
 
 constexpr uint32_t TEST_LOADS = 4;   // 16-byte entry loads in flight per thread (8 measured slower: 6.1 vs 5.9 ms)
 constexpr uint32_t TEST_GROUP = 32;  // chunks of a leaf whose buckets are streamed as one sequence
-// A task = (column, tile): the block loads that 128 KiB tile of the column's filter into LDS and tests every probe binned
-// for it.  The tasks are software-pipelined: while task i's entries stream, the tile of task i + 1 is already on its way
-// into registers and its bucket descriptors into the other half of the descriptor arrays (a tile takes >= 5 us at the
-// per-CU load rate; trees with few pairs per leaf — subtree shards, thousands of leaves — spend most of a task there).
+// A task = (column, tile): the block loads that tile of the column's filter into LDS (128 KiB; 64 KiB with k-mer entries)
+// and tests every probe binned for it.  The tasks are software-pipelined: while task i's entries stream, the tile of task
+// i + 1 is already on its way into registers and its bucket descriptors into the other half of the descriptor arrays (a tile
+// takes >= 5 us at the per-CU load rate; trees with few pairs per leaf — subtree shards, thousands of leaves — spend most of
+// a task there).
+// COUNTS (thresholds < 1): an entry names a k-mer of its round (see TILE_LOG2_COUNTS); a probed bit that is 0 sets the
+// k-mer's byte in its chunk's miss array — position round_k0[chunk][round] + k-mer of the round, the table rows of the
+// group's chunks staged in LDS (and, like the tile, fetched while the previous task streams).
+template <bool COUNTS>
 __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
-    extern __shared__ uint32_t s_tile[];  // 2^TILE_LOG2 bits
-    __shared__ uint32_t s_pref[2][TEST_GROUP + 1], s_first[2][TEST_GROUP], s_misc[2][2];
-    __shared__ uint32_t s_failed[TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)];  // pairs of the group this block already reported
+    constexpr uint32_t TL = COUNTS ? TILE_LOG2_COUNTS : TILE_LOG2;
+    constexpr uint32_t TV = (1u << (TL - 5)) / 2048u;  // 8-byte loads per thread and tile
+    constexpr uint32_t RK = COUNTS ? MAX_ROUNDS : 1u;
+    extern __shared__ uint32_t s_tile[];  // 2^TL bits
+    __shared__ uint32_t s_pref[2][TEST_GROUP + 1], s_first[2][TEST_GROUP], s_misc[2][2], s_kbase[2][TEST_GROUP];
+    __shared__ uint32_t s_failed[COUNTS ? 1 : (TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5))];  // pairs of the group this block already reported
+    __shared__ uint32_t s_rk0[COUNTS ? TEST_GROUP : 1][RK];                               // round_k0 rows of the group's chunks
     __shared__ unsigned long long s_base[2][TEST_GROUP];
-    const uint32_t tile_words = 1u << (TILE_LOG2 - 5);
+    const uint32_t tile_words = 1u << (TL - 5);
     const uint64_t n_words32 = a.n_words * 2;
     const uint64_t n_tasks = (uint64_t)a.n_leaves * a.n_tiles;
     const uint32_t n_chunks = *a.n_chunks < a.max_chunks ? *a.n_chunks : a.max_chunks;
@@ -1526,6 +1593,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
         if (i < TEST_GROUP) {
             s_pref[buf][i + 1] = incl;
             s_first[buf][i] = dsc.first;
+            s_kbase[buf][i] = dsc.kbase;
             s_base[buf][i] = dsc.base + (uint64_t)t * dsc.cap;
         }
         const uint64_t mm = ballot64(mine);
@@ -1535,53 +1603,95 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
         }
     };
     // the column's tile: words [t * tile_words, ...) of its filter row (zero beyond the filter's end); filter rows are only
-    // 8-byte aligned: 8-byte loads, all sixteen of a thread in flight
-    auto tile_loads = [&](uint32_t leaf, uint32_t t, uint2 (&v)[16]) {
+    // 8-byte aligned: 8-byte loads, all of a thread in flight
+    auto tile_loads = [&](uint32_t leaf, uint32_t t, uint2 (&v)[TV]) {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)a.col_row[leaf] * a.n_words);
         const uint64_t w0 = (uint64_t)t * tile_words;
 #pragma unroll
-        for (uint32_t u = 0; u < 16; ++u) {
+        for (uint32_t u = 0; u < TV; ++u) {
             const uint32_t i = threadIdx.x * 2 + u * 2048u;
             v[u] = (w0 + i + 1 < n_words32) ? *reinterpret_cast<const uint2 *>(src + w0 + i) : make_uint2(0, 0);
         }
     };
-    auto tile_store = [&](const uint2 (&v)[16]) {
+    auto tile_store = [&](const uint2 (&v)[TV]) {
 #pragma unroll
-        for (uint32_t u = 0; u < 16; ++u) *reinterpret_cast<uint2 *>(s_tile + threadIdx.x * 2 + u * 2048u) = v[u];
-        for (uint32_t i = threadIdx.x; i < (TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)); i += blockDim.x) s_failed[i] = 0;
+        for (uint32_t u = 0; u < TV; ++u) *reinterpret_cast<uint2 *>(s_tile + threadIdx.x * 2 + u * 2048u) = v[u];
+        if (!COUNTS)
+            for (uint32_t i = threadIdx.x; i < (TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)); i += blockDim.x) s_failed[i] = 0;
+    };
+    // COUNTS: the round_k0 rows of the 32 chunks from g0 on: 32 threads per chunk, 8 rounds per thread (rounds the chunk
+    // did not have — and chunks of other columns — are never looked up)
+    auto rk_loads = [&](uint32_t g0, uint4 (&rk)[2]) {
+        const uint32_t c = g0 + (threadIdx.x >> 5), r0 = (threadIdx.x & 31u) * 8u;
+        rk[0] = rk[1] = make_uint4(0, 0, 0, 0);
+        if (COUNTS && c < n_chunks && r0 < a.n_rounds[c]) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.round_k0 + (uint64_t)c * MAX_ROUNDS + r0);
+            rk[0] = src[0];
+            rk[1] = src[1];
+        }
+    };
+    auto rk_store = [&](const uint4 (&rk)[2]) {
+        if (COUNTS) {
+            uint4 *dst = reinterpret_cast<uint4 *>(&s_rk0[threadIdx.x >> 5][(threadIdx.x & 31u) * 8u]);
+            dst[0] = rk[0];
+            dst[1] = rk[1];
+        }
     };
     // 16 entries in flight per thread as four 16-byte loads (buckets start on 128-byte boundaries, their fill marks are
-    // multiples of four entries: a load never straddles two buckets; k_tile_bin pads its runs with ENTRY_PAD)
+    // multiples of four entries: a load never straddles two buckets; k_tile_bin pads its runs)
     auto stream = [&](uint32_t buf) {
         const uint32_t total = s_pref[buf][TEST_GROUP];
         uint32_t ci = 0;  // bucket of the thread's current position (positions only grow)
         for (uint32_t v0 = threadIdx.x * 4u; v0 < total; v0 += blockDim.x * 4u * TEST_LOADS) {
             uint4 en[TEST_LOADS];
             uint32_t first[TEST_LOADS], cidx[TEST_LOADS];
+            bool have[TEST_LOADS];
 #pragma unroll
             for (uint32_t u = 0; u < TEST_LOADS; ++u) {
                 const uint32_t v = v0 + u * blockDim.x * 4u;
                 en[u] = make_uint4(ENTRY_PAD, ENTRY_PAD, ENTRY_PAD, ENTRY_PAD);
                 first[u] = 0;
                 cidx[u] = 0;
-                if (v < total) {
+                have[u] = v < total;
+                if (have[u]) {
                     while (v >= s_pref[buf][ci + 1]) ++ci;
                     en[u] = *reinterpret_cast<const uint4 *>(a.entries + s_base[buf][ci] + (v - s_pref[buf][ci]));
                     first[u] = s_first[buf][ci];
-                    cidx[u] = ci << CHUNK_PAIRS_LOG2;
+                    cidx[u] = COUNTS ? ci : ci << CHUNK_PAIRS_LOG2;
                 }
             }
 #pragma unroll
             for (uint32_t u = 0; u < TEST_LOADS; ++u) {
                 const uint32_t ev[4] = {en[u].x, en[u].y, en[u].z, en[u].w};
+                if (COUNTS) {
+                    if (!have[u]) continue;
+                    uint32_t bad = 0;
 #pragma unroll
-                for (uint32_t c = 0; c < 4; ++c) {
-                    const uint32_t off = ev[c] & ((1u << TILE_LOG2) - 1u);
-                    if (ev[c] != ENTRY_PAD && !((s_tile[off >> 5] >> (off & 31u)) & 1u)) {
-                        // a probed bit is 0: the pair fails.  A failing pair usually has hundreds of such probes (every
-                        // k-mer over a sequencing error): only the first one this block sees goes to memory.
-                        const uint32_t lp = ev[c] >> TILE_LOG2, fb = cidx[u] + lp;
-                        if (!(atomicOr(&s_failed[fb >> 5], 1u << (fb & 31u)) & (1u << (fb & 31u)))) atomicOr(&a.fail[first[u] + lp], 1u);
+                    for (uint32_t c = 0; c < 4; ++c) {
+                        const uint32_t off = ev[c] & ((1u << TL) - 1u);
+                        bad |= (((s_tile[off >> 5] >> (off & 31u)) & 1u) ^ 1u) << c;
+                    }
+                    if (bad) {
+                        const uint32_t rho = (ev[0] >> 30) | ((ev[1] >> 30) << 2) | ((ev[2] >> 30) << 4) | ((ev[3] >> 30) << 6);
+                        const uint32_t kb = s_rk0[cidx[u]][rho], wb = s_kbase[buf][cidx[u]];
+#pragma unroll
+                        for (uint32_t c = 0; c < 4; ++c) {
+                            if (!((bad >> c) & 1u)) continue;
+                            // a plain byte store: idempotent, no read-modify-write (device-scope atomics are performed at
+                            // the memory side on this part — 2.7 G/s when a k-mer over a sequencing error fails in ten tiles)
+                            a.kmiss[(uint64_t)wb + kb + ((ev[c] >> TL) & ((1u << ROUND_KMERS_LOG2) - 1u))] = 1;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; ++c) {
+                        const uint32_t off = ev[c] & ((1u << TL) - 1u);
+                        if (ev[c] != ENTRY_PAD && !((s_tile[off >> 5] >> (off & 31u)) & 1u)) {
+                            // a probed bit is 0: the pair fails.  A failing pair usually has hundreds of such probes (every
+                            // k-mer over a sequencing error): only the first one this block sees goes to memory.
+                            const uint32_t lp = ev[c] >> TL, fb = cidx[u] + lp;
+                            if (!(atomicOr(&s_failed[fb >> 5], 1u << (fb & 31u)) & (1u << (fb & 31u)))) atomicOr(&a.fail[first[u] + lp], 1u);
+                        }
                     }
                 }
             }
@@ -1593,10 +1703,13 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     uint32_t buf = 0;
     {
         const uint32_t leaf = (uint32_t)(task / a.n_tiles), t = (uint32_t)(task % a.n_tiles);
-        uint2 v[16];
+        uint2 v[TV];
+        uint4 rk[2];
         tile_loads(leaf, t, v);
+        rk_loads(a.leaf_chunk0[leaf], rk);
         if (threadIdx.x < 64) describe(0, leaf, t, a.leaf_chunk0[leaf]);
         tile_store(v);
+        rk_store(rk);
         __syncthreads();
     }
     while (task < n_tasks) {
@@ -1604,20 +1717,31 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
         const uint64_t nxt = valid_task(task + gridDim.x);
         const bool have_nxt = nxt < n_tasks;
         const uint32_t nleaf = have_nxt ? (uint32_t)(nxt / a.n_tiles) : 0u, nt = have_nxt ? (uint32_t)(nxt % a.n_tiles) : 0u;
-        uint2 vn[16];
+        uint2 vn[TV];
+        uint4 rkn[2];
         if (have_nxt) tile_loads(nleaf, nt, vn);  // in flight while this task's entries stream
+        if (have_nxt) rk_loads(a.leaf_chunk0[nleaf], rkn);
         if (have_nxt && threadIdx.x < 64) describe(buf ^ 1u, nleaf, nt, a.leaf_chunk0[nleaf]);
         for (uint32_t g0 = a.leaf_chunk0[leaf];;) {
             stream(buf);
             if (s_misc[buf][0] < TEST_GROUP) break;  // (block-uniform) the column has no more chunks
-            g0 += TEST_GROUP;                         // (rare: more than 32 chunks for one column) the next 32, same tile
+            g0 += TEST_GROUP;                         // (more than 32 chunks for one column) the next 32, same tile
             __syncthreads();
             if (threadIdx.x < 64) describe(buf, leaf, t, g0);
-            for (uint32_t i = threadIdx.x; i < (TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)); i += blockDim.x) s_failed[i] = 0;
+            if (COUNTS) {
+                uint4 rk[2];
+                rk_loads(g0, rk);
+                rk_store(rk);
+            } else {
+                for (uint32_t i = threadIdx.x; i < (TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)); i += blockDim.x) s_failed[i] = 0;
+            }
             __syncthreads();
         }
         __syncthreads();  // everybody is done with this task's tile and descriptors; the next task's descriptors are written
-        if (have_nxt) tile_store(vn);
+        if (have_nxt) {
+            tile_store(vn);
+            rk_store(rkn);
+        }
         __syncthreads();
         task = nxt;
         buf ^= 1u;
@@ -1626,10 +1750,13 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
 void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        // (static LDS of the COUNTS build: the 32 KiB of round_k0 rows; static + dynamic must stay within the CU's 160 KiB)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << (TILE_LOG2_COUNTS - 3));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_tile_test, dim3((blocks + 1) / 2), dim3(1024), (size_t)(1u << (TILE_LOG2 - 3)), st, a);
+    if (a.counts) hipLaunchKernelGGL(k_tile_test<true>, dim3((blocks + 1) / 2), dim3(1024), (size_t)(1u << (TILE_LOG2_COUNTS - 3)), st, a);
+    else hipLaunchKernelGGL(k_tile_test<false>, dim3((blocks + 1) / 2), dim3(1024), (size_t)(1u << (TILE_LOG2 - 3)), st, a);
 }
 
 // Thresholds < 1 after the tile passes: the compact list of the pairs whose fail word is non-zero (a probe found 0, or the
@@ -1694,11 +1821,34 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
             uint64_t need = n;
             bool pass;
             if (a.miss_words) {  // thresholds < 1: contained k-mers = n - missing ones; query_passes (query.rs:38-49)
-                const unsigned long long *mw = a.miss_words + a.miss_pos[e];
-                const uint32_t nw = (uint32_t)((n + 63) >> 6);
                 uint64_t missing = 0;
+                // where the pair's miss bits are: in its chunk's bitmap when a launched LDS-tile pass binned it and nothing
+                // flagged it (bit 1 of the fail word), else in its own words, written by k_verify_rec
+                bool in_chunk = false;
+                uint32_t kbase = 0;
+                if (a.kmiss && !(a.fail[e] & 2u)) {
+                    const uint32_t c = a.pair_chunk[e];
+                    if (c != 0xffffffffu) {
+                        const ChunkDesc dsc = a.chunks[c];
+                        in_chunk = dsc.cap != 0 && dsc.pass < a.launched_passes;
+                        kbase = dsc.kbase;
+                    }
+                }
+                if (in_chunk) {  // bytes [s, s + n) of the chunk's miss array (0 or 1 each; the array starts 16-byte aligned)
+                    const uint32_t *kw = reinterpret_cast<const uint32_t *>(a.kmiss + kbase);
+                    const uint64_t s0 = a.pair_kpos[e], s1 = s0 + n;
+                    for (uint64_t w = s0 >> 2; w <= (s1 - 1) >> 2; ++w) {
+                        uint32_t v = kw[w];
+                        if (w == (s0 >> 2)) v &= ~0u << (8u * (uint32_t)(s0 & 3u));
+                        if (w == ((s1 - 1) >> 2)) v &= ~0u >> (8u * (3u - (uint32_t)((s1 - 1) & 3u)));
+                        missing += (uint64_t)__popc(v);
+                    }
+                } else {
+                    const unsigned long long *mw = a.miss_words + a.miss_pos[e];
+                    const uint32_t nw = (uint32_t)((n + 63) >> 6);
 #pragma unroll 4
-                for (uint32_t w = 0; w < nw; ++w) missing += (uint64_t)__popcll(mw[w]);
+                    for (uint32_t w = 0; w < nw; ++w) missing += (uint64_t)__popcll(mw[w]);
+                }
                 need = need_kmers(a.threshold, n);
                 pass = n - missing >= need;
                 dirty += missing != 0;

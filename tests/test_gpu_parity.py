@@ -343,15 +343,14 @@ def test_config2_shape_64_leaves_k21(gpu):
     noisy = seq.copy()
     where = rng.random(noisy.size - 16) < 0.02
     noisy[:-16][where] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(where.sum()))
-    # (PFQ_TILE_COUNTS=1: the LDS-tile passes sort out the pairs with no k-mer missing and the record kernel counts the
-    # rest — chosen on its own only when few pairs miss a k-mer, forced here with most pairs missing some; with a small
-    # entry buffer on top, chunks of passes that were not launched go to the record kernel as well)
+    # (the LDS-tile passes leave every k-mer that is not contained in the chunks' miss bitmaps; PFQ_TILE_COUNTS=0: the record
+    # kernel counts alone; with a small entry buffer, chunks of passes that were not launched go to the record kernel too)
     for thr in (0.3, 0.7):
         for v in range(ot.n_nodes):
             ot.mapped_reads[v] = 0
         oh, _, _ = orc.query_batch_packed(ot, noisy, off, thr, threads=8)
         want = np.array(oracle_hits(ot, oh), dtype=np.int64).reshape(-1, 2)
-        for env in ({}, {"PFQ_TILE_COUNTS": "1"}, {"PFQ_TILE_COUNTS": "1", "PFQ_TILE_ENTRIES": "6000000"}):
+        for env in ({}, {"PFQ_TILE_COUNTS": "0"}, {"PFQ_TILE_ENTRIES": "6000000"}, {"PFQ_TILE_ENTRIES": "40000"}):
             for key, val in env.items():
                 gt.set_option(key, val)
             try:
@@ -360,14 +359,14 @@ def test_config2_shape_64_leaves_k21(gpu):
                     gt.set_path(-1)
                     offs, leaves = gt.query_packed(noisy, off, thr, want_hits=True)
                     st = gt.last_stats()
-                    assert st.path == 1 and st.tile_mode == (1 if env else 0)
+                    assert st.path == 1 and st.tile_mode == (0 if "PFQ_TILE_COUNTS" in env else 1)
                     assert gt.get_leaf_counts() == ot.leaf_counts(), (thr, env, call)
                     got = np.stack([np.repeat(np.arange(n_reads), np.diff(offs).astype(np.int64)), leaves.astype(np.int64)], 1)
                     assert np.array_equal(got, want), (thr, env, call)
             finally:
                 for key in env:
                     gt.set_option(key, None)
-    # clean reads at a threshold below 1: after one call the tile passes are chosen without being asked for
+    # clean reads at a threshold below 1
     for v in range(ot.n_nodes):
         ot.mapped_reads[v] = 0
     oh, _, _ = orc.query_batch_packed(ot, seq, off, 0.5, threads=8)
