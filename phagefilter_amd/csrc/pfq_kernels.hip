@@ -106,7 +106,21 @@ __device__ __forceinline__ uint32_t screen_all(BlockLds &lds, uint32_t wave, con
 // misses > n - need.
 __device__ __forceinline__ void csa(uint32_t &hi, uint32_t &lo, uint32_t a, uint32_t b, uint32_t c) {
     const uint32_t u = a ^ b;
-    hi = (a & b) | (u & c);
+    hi = (u & c) | (~u & a);  // majority: where a and b differ c decides, else a — one v_bfi_b32
+    lo = u ^ c;
+}
+// Carry-save adder in three full-rate instructions: the majority is one bit-field insert (where a and b differ c decides,
+// else a), which the compiler does not form on its own (it builds the adder from five and / or / xor operations).
+// (v_bitop3_b32 would do each output in one instruction, but it is slow on gfx950: the dense counting screen took 31.6 ms
+// with two v_bitop3 per adder against 25.6 with the five plain operations.)
+__device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t x, uint32_t y) {  // (mask & x) | (~mask & y)
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ void csa3(uint32_t &hi, uint32_t &lo, uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t u = a ^ b;
+    hi = bfi32(u, c, a);
     lo = u ^ c;
 }
 template <uint32_t P, uint32_t BATCH>  // counter planes (counts up to 2^P - 1); rows per lane in flight
@@ -303,12 +317,13 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
 // 16 in the launch for long reads); other reads are returned in `irregular` for the per-read path.  The group is reads r0 .. r0+n-1, or
 // list[r0 .. r0+n-1] when a list is given; `rid` returns the lane's read.  On return live_out[j*rw + w] holds the
 // frontier words of read j and `survive` the reads with a non-empty frontier.
-template <uint32_t P>
+template <uint32_t P, uint32_t LPR_LOG2>  // counter planes; log2 of the lanes per read (rw = 4 << LPR_LOG2: 16, 32 or 64)
 __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const uint8_t *comp, uint32_t *live_out,
                                              const QueryArgs &a, const uint32_t *list, uint64_t r0, uint32_t n_in_group,
                                              uint32_t &survive, uint32_t &irregular, uint64_t &lane_len, uint64_t &rid) {
-    const uint32_t lane = lane_id(), k = a.hp.k, rw = a.rw;
-    const uint32_t lpr_log2 = a.rw_log2 - 2u, lpr = 1u << lpr_log2, rpw = 64u >> lpr_log2;
+    const uint32_t lane = lane_id(), k = a.hp.k;
+    static_assert(LPR_LOG2 >= 2 && LPR_LOG2 <= 4, "rows of 16, 32 or 64 words");
+    constexpr uint32_t lpr_log2 = LPR_LOG2, lpr = 1u << lpr_log2, rpw = 64u >> lpr_log2, rw = 4u << lpr_log2;
     const uint32_t j = lane >> lpr_log2, q = lane & (lpr - 1u);
     uint64_t o0 = 0, L = 0;
     rid = 0;
@@ -338,58 +353,72 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
             irregular |= 1u << ((uint32_t)l >> lpr_log2);
         }
     }
-    // dead: leaves (of my four dwords) whose miss count exceeded maxmiss.  The counters start at
-    // 2^P - 1 - maxmiss, so "misses > maxmiss" is the carry out of the top plane: no comparison is needed, and rows
-    // need no masking either (counters of dead leaves and of padding columns may wrap, they stay dead).
+    // Leaves (of my four dwords) die when their miss count exceeds maxmiss.  The counters start at 2^P - 1 - maxmiss, so
+    // "misses > maxmiss" is the carry out of the top plane: no comparison is needed, and rows need no masking either
+    // (counters of dead leaves and of padding columns may wrap, they stay dead).  Everything is kept COMPLEMENTED — counter
+    // planes, carries, and `live` = ~dead: the misses to add are the complements of the rows, and majority and parity of
+    // complemented operands are the complements of majority and parity, so the adders take the rows as they come.
     // (columns that are no leaves start out dead: no separate column mask has to stay in registers)
-    uint32_t dead[4];
+    uint32_t live[4];
     const uint32_t bias = regular ? ((1u << P) - 1u - maxmiss) : 0u;
-    uint32_t c[P][4];
+    uint32_t c[P][4];  // complements of the counter planes
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const uint32_t w = q * 4u + u;
         uint32_t cmu = (w * 32u < a.n_leaves) ? ((a.n_leaves - w * 32u >= 32u) ? ~0u : ((1u << (a.n_leaves - w * 32u)) - 1u)) : 0u;
         if (!regular) cmu = 0u;
-        dead[u] = ~cmu;
+        live[u] = cmu;
 #pragma unroll
-        for (uint32_t p = 0; p < P; ++p) c[p][u] = ((bias >> p) & 1u) ? ~0u : 0u;
+        for (uint32_t p = 0; p < P; ++p) c[p][u] = ((bias >> p) & 1u) ? 0u : ~0u;
     }
     uint8_t *fwd = reinterpret_cast<uint8_t *>(fw), *rcb = reinterpret_cast<uint8_t *>(rw_);
     const uint32_t stride = (DENSE_READS / rpw) * MINI_BYTES;  // bytes of LDS per read and direction (rpw <= 16)
     const uint32_t base = j * stride + WIN_PAD;
     bool alive = regular;  // my read still has a live leaf
+    // The bytes of a read are staged a segment at a time — as many k-mers as the read's share of the LDS holds, 128 of a
+    // 150 bp read at k = 21 — so that a pass needs no global load of its own (a round trip per pass of eight k-mers before).
+    const uint32_t seg_cap = stride - 2u * WIN_PAD;
+    const uint32_t seg_kmers = ((seg_cap - k + 1u) / lpr) * lpr;  // (>= lpr: stride >= 84 bytes, k <= 64, lpr <= stride / 21)
+    uint32_t seg_pos = 0, W = 0;  // first k-mer of the staged segment; bytes staged for my read
     for (uint32_t pos = 0;; pos += lpr) {
         const bool active = alive && pos < n_scr;
         if (ballot64(active) == 0) break;
-        const uint32_t nk = active ? (n - pos < lpr ? n - pos : lpr) : 0u;
-        const uint32_t W = nk ? nk + k - 1u : 0u;  // bytes staged for my read: <= lpr + KMAX - 1
-        __builtin_amdgcn_wave_barrier();
-        // six bytes per lane and batch; the loads are unconditional (clamped address) so that none waits for another
-        const uint8_t *src = a.seq + (active ? o0 + pos : 0ull);
-        for (uint32_t i0 = 0; i0 < k + lpr - 1u; i0 += 6u * lpr) {
-            uint8_t b[6];
+        if (pos - seg_pos >= seg_kmers || pos == 0) {  // (wave-uniform)
+            seg_pos = pos;
+            const uint32_t kn = active ? (n_scr - pos < seg_kmers ? n_scr - pos : seg_kmers) : 0u;
+            W = kn ? kn + k - 1u : 0u;
+            __builtin_amdgcn_wave_barrier();
+            // six bytes per lane and batch; the loads are unconditional (clamped address) so that none waits for another
+            const uint8_t *src = a.seq + (active ? o0 + pos : 0ull);
+            for (uint32_t i0 = 0; i0 < k + seg_kmers - 1u; i0 += 6u * lpr) {
+                if (ballot64(i0 < W) == 0) break;
+                uint8_t b[6];
 #pragma unroll
-            for (uint32_t u = 0; u < 6; ++u) {
-                const uint32_t idx = i0 + lpr * u + q;
-                b[u] = src[idx < W ? idx : 0u];
-            }
+                for (uint32_t u = 0; u < 6; ++u) {
+                    const uint32_t idx = i0 + lpr * u + q;
+                    b[u] = src[idx < W ? idx : 0u];
+                }
 #pragma unroll
-            for (uint32_t u = 0; u < 6; ++u) {
-                const uint32_t idx = i0 + lpr * u + q;
-                if (idx < W) {
-                    fwd[base + idx] = b[u];
-                    rcb[base + (W - 1u - idx)] = comp[b[u]];
+                for (uint32_t u = 0; u < 6; ++u) {
+                    const uint32_t idx = i0 + lpr * u + q;
+                    if (idx < W) {
+                        fwd[base + idx] = b[u];
+                        rcb[base + (W - 1u - idx)] = comp[b[u]];
+                    }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
+        const uint32_t x = pos - seg_pos + q;  // my k-mer's place in the segment
+        const uint32_t nk = active ? (n_scr - pos < lpr ? n_scr - pos : lpr) : 0u;
         const bool valid = q < nk;
         uint64_t h1, h2;
-        kmer_hashes_at(fw, rw_, base + q, base + (W - q - k), valid, a.hp, h1, h2);
+        kmer_hashes_at(fw, rw_, base + x, base + (W - x - k), valid, a.hp, h1, h2);
         // row indices of the wave go through LDS (live_out is free until the end): a lane fetches the eight of its
         // read with two 16-byte reads; k-mers that do not exist point at the all-ones row behind S (no miss)
         live_out[lane] = valid ? mod_d(h1, a.hp) : a.ones_row;
         __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
         for (uint32_t t0 = 0; t0 < lpr; t0 += 8u) {
             const uint4 xa = *reinterpret_cast<const uint4 *>(live_out + (j << lpr_log2) + t0);
             const uint4 xb = *reinterpret_cast<const uint4 *>(live_out + (j << lpr_log2) + t0 + 4u);
@@ -398,24 +427,25 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
 #pragma unroll
             for (uint32_t u = 0; u < 8; ++u) {
                 const uint32_t x = (t0 + u < lpr) ? xs[u] : a.ones_row;  // lpr == 4: the upper four belong to the next read
-                m[u] = *reinterpret_cast<const uint4 *>(a.S + ((uint64_t)x << a.rw_log2) + q * 4u);
+                m[u] = *reinterpret_cast<const uint4 *>(a.S + ((uint64_t)x << (lpr_log2 + 2u)) + q * 4u);
             }
 #define PFQ_CSA_WORD(F, W_)                                                   \
     {                                                                         \
-        uint32_t t2a, t2b, t4a, t4b, t8;                                      \
-        csa(t2a, c[0][W_], c[0][W_], ~m[0].F, ~m[1].F);                       \
-        csa(t2b, c[0][W_], c[0][W_], ~m[2].F, ~m[3].F);                       \
-        csa(t4a, c[1][W_], c[1][W_], t2a, t2b);                               \
-        csa(t2a, c[0][W_], c[0][W_], ~m[4].F, ~m[5].F);                       \
-        csa(t2b, c[0][W_], c[0][W_], ~m[6].F, ~m[7].F);                       \
-        csa(t4b, c[1][W_], c[1][W_], t2a, t2b);                               \
-        csa(t8, c[2][W_], c[2][W_], t4a, t4b);                                \
+        uint32_t t2a, t2b, t4a, t4b, t8;  /* complements of the carries */    \
+        csa3(t2a, c[0][W_], c[0][W_], m[0].F, m[1].F);                        \
+        csa3(t2b, c[0][W_], c[0][W_], m[2].F, m[3].F);                        \
+        csa3(t4a, c[1][W_], c[1][W_], t2a, t2b);                              \
+        csa3(t2a, c[0][W_], c[0][W_], m[4].F, m[5].F);                        \
+        csa3(t2b, c[0][W_], c[0][W_], m[6].F, m[7].F);                        \
+        csa3(t4b, c[1][W_], c[1][W_], t2a, t2b);                              \
+        csa3(t8, c[2][W_], c[2][W_], t4a, t4b);                               \
         _Pragma("unroll") for (uint32_t p = 3; p < P; ++p) {                  \
-            const uint32_t carry = c[p][W_] & t8;                             \
-            c[p][W_] ^= t8;                                                   \
+            uint32_t carry = c[p][W_] | t8;         /* ~(plane & carry) */    \
+            c[p][W_] = ~(c[p][W_] ^ t8);            /* ~(plane ^ carry) */    \
+            asm("" : "+v"(carry));  /* (else the compiler folds two steps into one v_bitop3_b32, which is slow) */ \
             t8 = carry;                                                       \
         }                                                                     \
-        dead[W_] |= t8;                                                       \
+        live[W_] &= t8;                                                       \
     }
             PFQ_CSA_WORD(x, 0)
             PFQ_CSA_WORD(y, 1)
@@ -423,13 +453,10 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
             PFQ_CSA_WORD(w, 3)
 #undef PFQ_CSA_WORD
         }
-        uint32_t any = ~(dead[0] & dead[1] & dead[2] & dead[3]);
+        uint32_t any = live[0] | live[1] | live[2] | live[3];
         for (uint32_t sft = 1; sft < lpr; sft <<= 1) any |= (uint32_t)__shfl_xor((int)any, (int)sft);
         alive = alive && any != 0;
     }
-    uint32_t live[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) live[u] = ~dead[u];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < 4; ++u) live_out[j * rw + q * 4u + u] = live[u];
@@ -452,8 +479,11 @@ __device__ __forceinline__ bool has_batched_tail(uint64_t n) {
 }
 
 // ---- the classification kernel ---------------------------------------------------------------------------------------
-template <bool DEFER, bool COUNTS, bool LONG = false>
-__global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
+// LPR_LOG2 (thresholds < 1): log2 of the lanes per read of the dense counting screen, rw = 4 << LPR_LOG2 (16, 32 or 64 row
+// words: a build per row width keeps the screen free of run-time shapes); 0: rows narrower than 16 words, per-read screen.
+// (the counting build is held to three waves per SIMD — 168 VGPRs; the allocator stops a few registers above on its own)
+template <bool DEFER, bool COUNTS, bool LONG = false, uint32_t LPR_LOG2 = 0>
+__global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0) ? 3 : 1) k_classify(QueryArgs a) {
     __shared__ BlockLds lds;
     __shared__ DenseLds<(DEFER && !LONG) || COUNTS> dlds;
     fill_complement(lds.comp);
@@ -606,7 +636,7 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
                 process_read(r0 + jj, nullptr);
             }
         }
-    } else if (COUNTS && !LONG && a.rw >= 16u) {
+    } else if constexpr (COUNTS && !LONG && LPR_LOG2 >= 2u) {
         // thresholds < 1: groups of 64/(rw/4) consecutive reads through the dense counting screen
         const uint32_t rpw = 256u >> a.rw_log2;
         const uint64_t n_groups = (a.n_reads + rpw - 1) / rpw;
@@ -615,8 +645,8 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             const uint32_t cnt = (uint32_t)(a.n_reads - r0 < rpw ? a.n_reads - r0 : rpw);
             uint64_t lane_len, rid;
             uint32_t survive, irregular;
-            dense_counts<8>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, nullptr, r0, cnt, survive,
-                            irregular, lane_len, rid);
+            dense_counts<8, LPR_LOG2>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, nullptr, r0, cnt, survive,
+                                      irregular, lane_len, rid);
             if (!(((survive | irregular) >> (lane >> (a.rw_log2 - 2u))) & 1u)) dense_bytes += lane_len;
             while (survive) {
                 const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
@@ -629,7 +659,7 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
                 process_read(r0 + jj, nullptr);
             }
         }
-    } else if (COUNTS && LONG && a.rw >= 16u && a.ones_row != 0u) {
+    } else if constexpr (COUNTS && LONG && LPR_LOG2 >= 2u) {
         // the reads of >= 256 k-mers queued by the first launch: the same dense screen with 16 counter planes
         const uint32_t rpw = 256u >> a.rw_log2, lpr_log2 = a.rw_log2 - 2u;
         const uint64_t n_long = *a.n_long, n_groups = (n_long + rpw - 1) / rpw;
@@ -638,8 +668,8 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
             const uint32_t cnt = (uint32_t)(n_long - r0 < rpw ? n_long - r0 : rpw);
             uint64_t lane_len, rid;
             uint32_t survive, irregular;
-            dense_counts<NPLANES>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, a.long_list, r0, cnt,
-                                  survive, irregular, lane_len, rid);
+            dense_counts<NPLANES, LPR_LOG2>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, a.long_list, r0, cnt,
+                                            survive, irregular, lane_len, rid);
             if (!(((survive | irregular) >> (lane >> lpr_log2)) & 1u)) dense_bytes += lane_len;
             const uint32_t rid_lo = (uint32_t)rid;  // reads are indexed with 31 bits (query_device checks)
             while (survive) {
@@ -676,18 +706,29 @@ __global__ void __launch_bounds__(256) k_classify(QueryArgs a) {
     }
 }
 
+template <bool DEFER, uint32_t LPR_LOG2>
+static void launch_classify_counts(const QueryArgs &a, dim3 g, dim3 b, hipStream_t st) {
+    hipLaunchKernelGGL((k_classify<DEFER, true, false, LPR_LOG2>), g, b, 0, st, a);
+    hipLaunchKernelGGL((k_classify<DEFER, true, true, LPR_LOG2>), g, b, 0, st, a);  // the reads of >= 256 k-mers it queued
+}
 void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int blocks, hipStream_t st) {
     dim3 g(blocks), b(256);
+    if (!counts_mode) {
+        if (defer) hipLaunchKernelGGL((k_classify<true, false>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_classify<false, false>), g, b, 0, st, a);
+        return;
+    }
+    const uint32_t lp = (a.rw_log2 >= 4u && a.rw_log2 <= 6u) ? a.rw_log2 - 2u : 0u;
     if (defer) {
-        if (counts_mode) {
-            hipLaunchKernelGGL((k_classify<true, true>), g, b, 0, st, a);
-            hipLaunchKernelGGL((k_classify<true, true, true>), g, b, 0, st, a);
-        } else hipLaunchKernelGGL((k_classify<true, false>), g, b, 0, st, a);
+        if (lp == 2) launch_classify_counts<true, 2>(a, g, b, st);
+        else if (lp == 3) launch_classify_counts<true, 3>(a, g, b, st);
+        else if (lp == 4) launch_classify_counts<true, 4>(a, g, b, st);
+        else launch_classify_counts<true, 0>(a, g, b, st);
     } else {
-        if (counts_mode) {
-            hipLaunchKernelGGL((k_classify<false, true>), g, b, 0, st, a);
-            hipLaunchKernelGGL((k_classify<false, true, true>), g, b, 0, st, a);
-        } else hipLaunchKernelGGL((k_classify<false, false>), g, b, 0, st, a);
+        if (lp == 2) launch_classify_counts<false, 2>(a, g, b, st);
+        else if (lp == 3) launch_classify_counts<false, 3>(a, g, b, st);
+        else if (lp == 4) launch_classify_counts<false, 4>(a, g, b, st);
+        else launch_classify_counts<false, 0>(a, g, b, st);
     }
 }
 
@@ -1465,8 +1506,10 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
             // flush: every bin goes to its bucket as one run at the fill mark (kept in LDS: the block owns the chunk).  Sixteen
             // lanes per tile, four tiles per wave and pass, the 16-byte reads of a lane issued together: one LDS round trip
             // per batch instead of one per copy instruction (the block's waves flush in step, nothing else hides the latency).
-            for (uint32_t t0 = wave * 4u; t0 < a.n_tiles; t0 += BIN_WAVES * 4u) {
-                const uint32_t t = t0 + (lane >> 4), sl = lane & 15u;
+            // (bins of <= 256 entries — many tiles — hold ~150 per round: eight lanes per tile, eight tiles per wave and pass)
+            constexpr uint32_t LPT = BIN_CAP <= 256 ? 8 : 16, TPW = 64 / LPT, STEP = LPT * 4;
+            for (uint32_t t0 = wave * TPW; t0 < a.n_tiles; t0 += BIN_WAVES * TPW) {
+                const uint32_t t = t0 + lane / LPT, sl = lane % LPT;
                 const bool have = t < a.n_tiles;
                 const uint32_t cn = have ? cnt[t] : 0u, pos = have ? fillp[t] : 0u;
                 const uint32_t cc = cn < BIN_CAP ? cn : BIN_CAP, c4 = (cc + 3u) & ~3u;
@@ -1479,11 +1522,11 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                 uint32_t *dst = bucket0 + (uint64_t)(have ? t : 0u) * dsc.cap + pos;
                 constexpr uint32_t FB = 5;  // 16-byte reads in flight per lane: two batches cover a full bin (516 entries / 64)
                 const uint32_t wr_eff = (a.debug & 1u) ? 0u : wr;
-                for (uint32_t i0 = sl * 4u; i0 < wr; i0 += 64u * FB) {
+                for (uint32_t i0 = sl * 4u; i0 < wr; i0 += STEP * FB) {
                     uint4 v[FB];
 #pragma unroll
                     for (uint32_t u = 0; u < FB; ++u)  // (unconditional, clamped into the row: nothing waits for a branch)
-                        v[u] = *reinterpret_cast<const uint4 *>(row + min(i0 + u * 64u, BIN_STRIDE - 4u));
+                        v[u] = *reinterpret_cast<const uint4 *>(row + min(i0 + u * STEP, BIN_STRIDE - 4u));
 #pragma unroll
                     for (uint32_t u = 0; u < FB; ++u)  // (keeps the compiler from sinking every read next to its store)
                         asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
@@ -1498,12 +1541,12 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < FB; ++u)
-                        if (i0 + u * 64u < wr_eff) *reinterpret_cast<uint4 *>(dst + i0 + u * 64u) = v[u];
+                        if (i0 + u * STEP < wr_eff) *reinterpret_cast<uint4 *>(dst + i0 + u * STEP) = v[u];
                 }
                 if (!COUNTS)
-                    for (uint32_t i = wr + sl; i < cc; i += 16) flag_fallback(a, dsc.first + (row[i] >> TL));
+                    for (uint32_t i = wr + sl; i < cc; i += LPT) flag_fallback(a, dsc.first + (row[i] >> TL));
                 if (cn > BIN_CAP || (COUNTS && wr < cc)) {  // the LDS bin (or, with k-mer entries, the bucket) overflowed: whose probes were lost is unknown
-                    for (uint32_t i = sl; i < flush_P; i += 16) flag_fallback(a, dsc.first + flush_p + i);
+                    for (uint32_t i = sl; i < flush_P; i += LPT) flag_fallback(a, dsc.first + flush_p + i);
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (have && sl == 0 && cn) {
@@ -1835,14 +1878,22 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
                     }
                 }
                 if (in_chunk) {  // bytes [s, s + n) of the chunk's miss array (0 or 1 each; the array starts 16-byte aligned)
-                    const uint32_t *kw = reinterpret_cast<const uint32_t *>(a.kmiss + kbase);
+                    const uint4 *kw = reinterpret_cast<const uint4 *>(a.kmiss + kbase);
                     const uint64_t s0 = a.pair_kpos[e], s1 = s0 + n;
-                    for (uint64_t w = s0 >> 2; w <= (s1 - 1) >> 2; ++w) {
-                        uint32_t v = kw[w];
-                        if (w == (s0 >> 2)) v &= ~0u << (8u * (uint32_t)(s0 & 3u));
-                        if (w == ((s1 - 1) >> 2)) v &= ~0u >> (8u * (3u - (uint32_t)((s1 - 1) & 3u)));
-                        missing += (uint64_t)__popc(v);
+                    uint32_t cntb = 0;
+                    for (uint64_t q = s0 >> 4; q <= (s1 - 1) >> 4; ++q) {
+                        const uint4 v4 = kw[q];
+                        const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; ++i) {
+                            const uint64_t lo = (q << 4) + 4u * i;
+                            uint32_t m = ~0u;
+                            if (lo < s0) m = (s0 - lo >= 4) ? 0u : m << (8u * (uint32_t)(s0 - lo));
+                            if (lo + 4 > s1) m = (lo >= s1) ? 0u : m & (~0u >> (8u * (uint32_t)(lo + 4 - s1)));
+                            cntb += (uint32_t)__popc(vv[i] & m);
+                        }
                     }
+                    missing = cntb;
                 } else {
                     const unsigned long long *mw = a.miss_words + a.miss_pos[e];
                     const uint32_t nw = (uint32_t)((n + 63) >> 6);
