@@ -846,6 +846,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         ta.n_pairs_ptr = off + nb;
                         if (counts_mode) {
                             ta.counts = 1;
+                            ta.threshold = threshold;
                             ta.kmiss = t.d_kmiss.p;
                             ta.kmiss_cap = kmiss_cap;
                             ta.kmiss_used = t.d_cursors.p + 9;
@@ -877,6 +878,18 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         v.entry_cursor = t.d_cursors.p + 2;
                         v.entry_cap = ta.entry_cap;
                         v.launched_passes = (uint32_t)n_passes;
+                        if (counts_mode) {  // binned pairs whose prefix of k-mers leaves them undecided go to the record kernel
+                            pfq::FinalizeArgs pf{};
+                            pf.hp = t.hp;
+                            pf.threshold = threshold;
+                            pf.fail = t.d_fail.p;
+                            pf.kmiss = t.d_kmiss.p;
+                            pf.pair_kpos = t.d_pair_kpos.p;
+                            pf.pair_chunk = t.d_pair_chunk.p;
+                            pf.chunks = t.d_chunks.p;
+                            pf.launched_passes = (uint32_t)n_passes;
+                            pfq::launch_prefix_open(pf, t.d_meta.p, off + nb, t.d_fail.p, st);
+                        }
                         t.hint_entry_cap = ta.entry_cap;
                         t.last_passes = (uint32_t)std::max<uint64_t>(n_passes, 1);
                         if (ev) HIP_TRY(hipEventRecord(ev[4], st));

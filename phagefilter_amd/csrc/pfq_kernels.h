@@ -187,6 +187,7 @@ struct TileArgs {
     uint32_t flag_cap;
     const uint32_t *n_pairs_ptr;
     // thresholds < 1 (entries name k-mers, see TILE_LOG2_COUNTS)
+    float threshold;             // (which prefix of a read's k-mers is binned depends on it)
     uint32_t counts;             // 1: k-mer entries, 64 KiB tiles, miss bits; 0: pair entries, 128 KiB tiles, fail words
     uint8_t *kmiss;              // k-mer miss bytes of all chunks (a byte, not a bit: set with plain stores from any XCD)
     uint64_t kmiss_cap;          // its bytes, < 2^32 (chunks that find no room take the fallback)
@@ -213,6 +214,8 @@ void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st)
 // list = the sorted pairs with a non-zero fail word, in order within runs; *n_out += their number (thresholds < 1 after tile passes)
 void launch_collect_open(const uint32_t *fail, const uint32_t *n_pairs_ptr, uint32_t *list, uint32_t cap, unsigned int *n_out, hipStream_t st);
 void launch_finalize(const FinalizeArgs &a, hipStream_t st);
+// thresholds < 1 after tile passes with k-mer entries: flags (fail bit 1) the binned pairs whose prefix of k-mers does not decide them
+void launch_prefix_open(const FinalizeArgs &a, const uint4 *meta, const uint32_t *n_pairs_ptr, uint32_t *fail, hipStream_t st);
 
 void launch_insert(const HashParams &hp, const uint8_t *d_genomes, const uint64_t *d_goff, uint32_t n_genomes,
                    const uint32_t *d_leaf_row, uint64_t *bits, uint64_t n_words, hipStream_t st);

@@ -1162,6 +1162,60 @@ __global__ void __launch_bounds__(1024) k_verify_rec(VerifyArgs a) {
 //     the (chunk, tile) buckets in full runs; (3) test: a block loads one tile of one leaf into LDS (128 KiB) and tests
 //     all probes binned for it.  A probe found 0 sets bit 0 of the pair's fail word.  Whatever cannot be binned
 //     (bucket or entry buffer full) sets bit 1: those pairs are certified by k_verify_rec afterwards.
+// Thresholds < 1: a pair passes as soon as `need` of its k-mers are known to be contained, so the passes bin only a PREFIX
+// of every read's k-mers — need + slack, the slack covering the k-mers of two sequencing errors (or need / 2) — and a
+// pair whose prefix holds fewer than `need` contained k-mers is left to the record kernel, which counts all of them
+// (k_prefix_open flags it).  At threshold 0.3 that is 81 of the 130 k-mers of a 150 bp read.  Same result as counting
+// everything: the count only grows with more k-mers (query_passes, query.rs:38-49).
+__device__ __forceinline__ uint32_t prefix_kmers(float threshold, uint32_t n, uint32_t k) {
+    const uint64_t need = need_kmers(threshold, n);
+    const uint64_t slack = need / 2 > 2ull * k ? need / 2 : 2ull * k;
+    return need + slack < n ? (uint32_t)(need + slack) : n;
+}
+// Where a pair's miss information is after the tile passes with k-mer entries: in its chunk's miss bytes (true; kbase = the
+// chunk's first byte) when a launched pass binned it and nothing flagged it, else in its own miss words (k_verify_rec).
+__device__ __forceinline__ bool pair_in_chunk(const uint32_t *fail, const uint32_t *pair_chunk, const ChunkDesc *chunks,
+                                              uint32_t launched_passes, uint32_t e, uint32_t &kbase) {
+    if (fail[e] & 2u) return false;
+    const uint32_t c = pair_chunk[e];
+    if (c == 0xffffffffu) return false;
+    const ChunkDesc dsc = chunks[c];
+    kbase = dsc.kbase;
+    return dsc.cap != 0 && dsc.pass < launched_passes;
+}
+// bytes [s0, s1) of a chunk's miss array that are set (0 or 1 each; the array starts 16-byte aligned)
+__device__ __forceinline__ uint32_t count_miss_bytes(const uint8_t *kmiss, uint64_t s0, uint64_t s1) {
+    const uint4 *kw = reinterpret_cast<const uint4 *>(kmiss);
+    uint32_t cntb = 0;
+    for (uint64_t q = s0 >> 4; q <= (s1 - 1) >> 4; ++q) {
+        const uint4 v4 = kw[q];
+        const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            const uint64_t lo = (q << 4) + 4u * i;
+            uint32_t m = ~0u;
+            if (lo < s0) m = (s0 - lo >= 4) ? 0u : m << (8u * (uint32_t)(s0 - lo));
+            if (lo + 4 > s1) m = (lo >= s1) ? 0u : m & (~0u >> (8u * (uint32_t)(lo + 4 - s1)));
+            cntb += (uint32_t)__popc(vv[i] & m);
+        }
+    }
+    return cntb;
+}
+__global__ void __launch_bounds__(256) k_prefix_open(FinalizeArgs a, const uint4 *meta, const uint32_t *n_pairs_ptr, uint32_t *fail) {
+    const uint32_t n_pairs = *n_pairs_ptr;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_pairs; e += gridDim.x * blockDim.x) {
+        uint32_t kbase;
+        if (!pair_in_chunk(a.fail, a.pair_chunk, a.chunks, a.launched_passes, e, kbase)) continue;
+        const uint32_t n = meta[e].z - a.hp.k + 1, pn = prefix_kmers(a.threshold, n, a.hp.k);
+        if (pn == n) continue;  // everything was binned
+        const uint64_t s0 = a.pair_kpos[e];
+        const uint32_t missing = count_miss_bytes(a.kmiss + kbase, s0, s0 + pn);
+        if (pn - missing < need_kmers(a.threshold, n)) atomicOr(&fail[e], 2u);  // undecided: the record kernel counts all k-mers
+    }
+}
+void launch_prefix_open(const FinalizeArgs &a, const uint4 *meta, const uint32_t *n_pairs_ptr, uint32_t *fail, hipStream_t st) {
+    hipLaunchKernelGGL(k_prefix_open, dim3(2048), dim3(256), 0, st, a, meta, n_pairs_ptr, fail);
+}
 __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
     __shared__ unsigned long long s_sum;
     __shared__ uint32_t s_chunk0;
@@ -1181,7 +1235,8 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
         unsigned long long kmers = 0;
         const uint32_t chunk = chunk0 + ci;
         for (uint32_t e = first + threadIdx.x; e < first + n; e += blockDim.x) {
-            kmers += a.meta[e].z - a.hp.k + 1;
+            const uint32_t n_e = a.meta[e].z - a.hp.k + 1;
+            kmers += a.counts ? prefix_kmers(a.threshold, n_e, a.hp.k) : n_e;
             a.pair_chunk[e] = chunk < a.max_chunks ? chunk : 0xffffffffu;
         }
         for (int d = 32; d > 0; d >>= 1) kmers += __shfl_down(kmers, d);
@@ -1375,7 +1430,9 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
             r.p = p;
             r.koff = koff;
             const bool cand = lane < ROUND_PAIRS && p + lane < dsc.n;
-            const unsigned long long n64 = cand ? (unsigned long long)m.z - k + 1 - (lane == 0 ? koff : 0ull) : 0ull;
+            // (k-mer entries: only the prefix of the read's k-mers that decides nearly every pair, see prefix_kmers)
+            const uint32_t n_all = cand ? m.z - k + 1u : 0u, n_bin = (COUNTS && cand) ? prefix_kmers(a.threshold, n_all, k) : n_all;
+            const unsigned long long n64 = cand ? (unsigned long long)n_bin - (lane == 0 ? koff : 0ull) : 0ull;
             const uint32_t n_l = (uint32_t)(n64 > KB ? KB + 1u : n64);  // (more than the budget is all the same)
             uint32_t incl = n_l;
             for (uint32_t sft = 1; sft < ROUND_PAIRS; sft <<= 1) {
@@ -1865,35 +1922,15 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
             bool pass;
             if (a.miss_words) {  // thresholds < 1: contained k-mers = n - missing ones; query_passes (query.rs:38-49)
                 uint64_t missing = 0;
-                // where the pair's miss bits are: in its chunk's bitmap when a launched LDS-tile pass binned it and nothing
-                // flagged it (bit 1 of the fail word), else in its own words, written by k_verify_rec
-                bool in_chunk = false;
+                // where the pair's miss information is: in its chunk's miss bytes when a launched LDS-tile pass binned it and
+                // nothing flagged it (bit 1 of the fail word), else in its own words, written by k_verify_rec
                 uint32_t kbase = 0;
-                if (a.kmiss && !(a.fail[e] & 2u)) {
-                    const uint32_t c = a.pair_chunk[e];
-                    if (c != 0xffffffffu) {
-                        const ChunkDesc dsc = a.chunks[c];
-                        in_chunk = dsc.cap != 0 && dsc.pass < a.launched_passes;
-                        kbase = dsc.kbase;
-                    }
-                }
-                if (in_chunk) {  // bytes [s, s + n) of the chunk's miss array (0 or 1 each; the array starts 16-byte aligned)
-                    const uint4 *kw = reinterpret_cast<const uint4 *>(a.kmiss + kbase);
-                    const uint64_t s0 = a.pair_kpos[e], s1 = s0 + n;
-                    uint32_t cntb = 0;
-                    for (uint64_t q = s0 >> 4; q <= (s1 - 1) >> 4; ++q) {
-                        const uint4 v4 = kw[q];
-                        const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                        for (uint32_t i = 0; i < 4; ++i) {
-                            const uint64_t lo = (q << 4) + 4u * i;
-                            uint32_t m = ~0u;
-                            if (lo < s0) m = (s0 - lo >= 4) ? 0u : m << (8u * (uint32_t)(s0 - lo));
-                            if (lo + 4 > s1) m = (lo >= s1) ? 0u : m & (~0u >> (8u * (uint32_t)(lo + 4 - s1)));
-                            cntb += (uint32_t)__popc(vv[i] & m);
-                        }
-                    }
-                    missing = cntb;
+                const bool in_chunk = a.kmiss && pair_in_chunk(a.fail, a.pair_chunk, a.chunks, a.launched_passes, e, kbase);
+                uint64_t n_seen = n;  // k-mers the count is about
+                if (in_chunk) {  // the binned prefix of the read's k-mers (k_prefix_open saw to it that it decides the pair)
+                    n_seen = prefix_kmers(a.threshold, (uint32_t)n, a.hp.k);
+                    const uint64_t s0 = a.pair_kpos[e];
+                    missing = count_miss_bytes(a.kmiss + kbase, s0, s0 + n_seen);
                 } else {
                     const unsigned long long *mw = a.miss_words + a.miss_pos[e];
                     const uint32_t nw = (uint32_t)((n + 63) >> 6);
@@ -1901,7 +1938,7 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
                     for (uint32_t w = 0; w < nw; ++w) missing += (uint64_t)__popcll(mw[w]);
                 }
                 need = need_kmers(a.threshold, n);
-                pass = n - missing >= need;
+                pass = n_seen - missing >= need;
                 dirty += missing != 0;
             } else pass = !(a.fail[e] & 1u);
             if (a.guards) {  // a guard that does not pass takes its leaf pair with it (query.rs:119-141: children are only
