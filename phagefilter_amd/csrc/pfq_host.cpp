@@ -80,7 +80,7 @@ struct DevBuf {
 struct Knobs {
     long long record_gb = -1, tile_gb = -1, tile_entries = -1, slice_kb = -1;
     long long verify_blocks = -1, verify_chunk = -1, verify_sub = -1, verify_threads = -1, bin_blocks = -1, test_blocks = -1;
-    long long tile = -1, tile_counts = -1, no_tail_batch = -1, bin_narrow = -1, bin_wide = -1, bin_debug = -1;
+    long long tile = -1, tile_counts = -1, no_tail_batch = -1, bin_narrow = -1, bin_wide = -1, bin_debug = -1, block = -1;
 };
 struct KnobName {
     const char *name;
@@ -95,6 +95,7 @@ const KnobName KNOBS[] = {
     {"PFQ_TILE", &Knobs::tile},                 {"PFQ_TILE_COUNTS", &Knobs::tile_counts},
     {"PFQ_NO_TAIL_BATCH", &Knobs::no_tail_batch}, {"PFQ_BIN_NARROW", &Knobs::bin_narrow},
     {"PFQ_BIN_WIDE", &Knobs::bin_wide},         {"PFQ_BIN_DEBUG", &Knobs::bin_debug},
+    {"PFQ_BLOCK", &Knobs::block},
 };
 bool set_knob(Knobs &k, const char *name, const char *value) {
     for (const KnobName &kn : KNOBS)
@@ -163,6 +164,10 @@ struct pfq_tree {
     DevBuf<pfq::ChunkDesc> d_chunks;
     DevBuf<unsigned int> d_gfill, d_binq;
     DevBuf<uint8_t> d_kmiss;
+    DevBuf<uint8_t> d_T, d_failb;      // block mode: byte-per-index tables of the blocks of 8 leaves; failure bytes per (pair, leaf)
+    bool tables_valid = false;         // d_T matches the current leaf set
+    double cand_per_read = 1.0;        // candidate leaves per read seen by recent calls (related genomes: several): chooses block mode
+    uint32_t last_block_mode = 0;
     DevBuf<uint32_t> d_round_k0, d_n_rounds, d_pair_kpos;  // thresholds < 1: LDS-tile passes with k-mer entries
     uint32_t last_tile_mode = 0, last_passes = 1;
     DevBuf<uint2> d_hit_pairs, d_pairs, d_sorted;
@@ -497,6 +502,7 @@ int build_layout(pfq_tree &t) {
     t.group_stride = ((uint64_t)t.n_words * 64 + 1) * t.rw;  // + the all-ones row of the group
     if (nl == 0) {
         t.layout_valid = true;
+        t.tables_valid = false;
         return PFQ_OK;
     }
     const size_t s_words = (size_t)t.group_stride * t.n_groups;
@@ -522,6 +528,7 @@ int build_layout(pfq_tree &t) {
     pfq::launch_transpose(t.d_bits.p, t.n_words, t.d_col_row.p, t.n_cols, t.d_S.p, t.rw, t.group_stride, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
+    t.tables_valid = false;
     t.layout_valid = true;
     return PFQ_OK;
 }
@@ -562,6 +569,7 @@ bool ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads, bool with_guards) {
         t.pairs_per_read = std::max(t.pairs_per_read, (double)t.h_pair_cursor[0] / (double)t.hint_reads);
         if (t.hint_entry_cap) t.passes_hint = std::max<uint64_t>(1, (t.h_pair_cursor[1] + t.hint_entry_cap - 1) / t.hint_entry_cap);
         if (t.hint_counts) t.dirty_frac = (double)t.h_pair_cursor[2] / (double)std::max<unsigned long long>(1, t.h_pair_cursor[3] & 0xffffffffull);
+        t.cand_per_read = (double)t.h_pair_cursor[4] / (double)t.hint_reads;
         t.hint_reads = 0;
     }
     (void)hipGetLastError();  // hipEventQuery reports "not ready" through the error state
@@ -604,7 +612,8 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     t.have_last_stream = true;
     t.last_n_reads = n_reads;
     PFQ_TRY(ensure_scratch(t, n_reads, want_hits));
-    const size_t nl = t.leaves.size(), nc = t.n_cols;  // leaf columns; leaf + guard columns (= buckets of the bucketed path)
+    const size_t nl = t.leaves.size();
+    size_t nc = t.n_cols;  // leaf + guard columns = buckets of the bucketed path (block mode: blocks of 8 leaf columns)
     const bool with_guards = !t.guard_col.empty();
     // bucketed path: threshold 1 (any certificate kernel), or 0 < threshold < 1 with probe records (per-pair k-mer miss bits)
     const bool thr_one = threshold == 1.0f, thr_frac = threshold > 0.0f && threshold < 1.0f;
@@ -626,6 +635,17 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     if (bucketed && recs_possible && !soft_ensure(t.d_meta, t.d_pairs.n)) recs_possible = false;
     if (bucketed && thr_frac && !recs_possible) bucketed = false;
     const bool counts_mode = !(threshold >= 1.0f);  // theta >= 1: need >= n for every read with k-mers
+    // Block mode (pfq::TILE_LOG2_BLOCK): reads that pass several leaves of a block of 8 (strains of one phage) are certified
+    // once per block.  Threshold 1, no guard columns, records and room for the tables; chosen when recent calls saw more
+    // than 1.5 candidate leaves per read (PFQ_BLOCK=1 / 0 forces / forbids it).  Results do not depend on the choice.
+    const uint64_t n_blocks = (nl + 7) / 8;
+    const uint32_t n_tiles_block = (uint32_t)((t.n_words * 64 + (1ull << pfq::TILE_LOG2_BLOCK) - 1) >> pfq::TILE_LOG2_BLOCK);
+    bool block_mode = bucketed && thr_one && !with_guards && recs_possible && n_tiles_block <= 560 && n_blocks < (1u << 24) &&
+                      (kn.block >= 0 ? kn.block != 0 : t.cand_per_read > 1.5) && (kn.tile < 0 || kn.tile != 0);
+    if (block_mode && !soft_ensure(t.d_T, n_blocks * t.n_words * 64)) block_mode = false;
+    if (block_mode && !soft_ensure(t.d_failb, t.d_pairs.n * 8)) block_mode = false;
+    if (block_mode) nc = n_blocks;
+    t.last_block_mode = 0;
     uint64_t miss_cap = 0;
     size_t nb = 0;
     uint32_t sub_log2 = 0;
@@ -730,6 +750,14 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 if (with_guards) HIP_TRY(hipMemsetAsync(t.d_gfail.p, 0, t.d_gfail.n * 4, st));
                 HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 128 * 4, st));
                 a.batch_tails = (recs && !counts_mode && kn.no_tail_batch <= 0) ? 1u : 0u;
+                a.block_pairs = block_mode ? 1u : 0u;
+                if (block_mode) {
+                    if (!t.tables_valid) {  // (the leaf set changed, or first use)
+                        pfq::launch_block_tables(t.d_bits.p, t.n_words, t.d_col_row.p, (uint32_t)nl, t.d_T.p, st);
+                        t.tables_valid = true;
+                    }
+                    HIP_TRY(hipMemsetAsync(t.d_failb.p, 0, t.d_failb.n, st));
+                }
                 PFQ_TRY(classify_groups(true));
                 pfq::GuardArgs ga{};
                 if (with_guards) {  // every guard of a deferred pair's leaf becomes a pair of its own (second region of the buffer)
@@ -746,7 +774,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nb, st);
                 if (counts_mode) pfq::launch_bucket_scan(cntw, offw, curw, (uint32_t)nb, st);
                 pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, sub_log2, t.d_sorted.p,
-                                           recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, offw, curw,
+                                           recs ? t.d_meta.p : nullptr, d_off, block_mode ? nullptr : t.d_col_row.p, offw, curw,
                                            counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
                                            with_guards ? t.d_owner.p : nullptr, with_guards ? t.d_owner_sorted.p : nullptr, 1024, st);
                 if (with_guards)
@@ -786,13 +814,14 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 // LDS-tile certificates: every probe binned by (leaf chunk, 128 KiB filter tile), tiles tested out of LDS;
                 // k_verify_rec then only sees the pairs that could not be binned
                 // (thresholds < 1: entries name k-mers, tiles are half the size — pfq::TILE_LOG2_COUNTS)
-                const uint32_t tile_log2 = counts_mode ? pfq::TILE_LOG2_COUNTS : pfq::TILE_LOG2;
+                const uint32_t tile_log2 = counts_mode ? pfq::TILE_LOG2_COUNTS : (block_mode ? pfq::TILE_LOG2_BLOCK : pfq::TILE_LOG2);
                 const uint32_t n_tiles = (uint32_t)((t.n_words * 64 + (1ull << tile_log2) - 1) >> tile_log2);
+                const uint32_t chunk_log2 = block_mode ? pfq::CHUNK_PAIRS_LOG2_BLOCK : pfq::CHUNK_PAIRS_LOG2;
                 // Thresholds < 1: the tile passes leave the k-mers that are not contained in per-chunk miss bitmaps; k_verify_rec
                 // only sees what could not be binned.  (PFQ_TILE_COUNTS=0: record kernel only.)  Results do not depend on the choice.
                 bool tile_counts = true;
                 if (kn.tile_counts >= 0) tile_counts = kn.tile_counts != 0;
-                bool tile_mode = recs && (!counts_mode || tile_counts) && n_tiles < pfq::MAX_TILES;
+                bool tile_mode = recs && (!counts_mode || tile_counts) && (block_mode || n_tiles < 256);
                 if (kn.tile >= 0) tile_mode = tile_mode && kn.tile != 0;
                 if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = 0; }
                 uint64_t tile_budget = std::min<uint64_t>(64ull << 30, (uint64_t)((double)(mem_free + t.d_entries.bytes()) * 0.8));
@@ -800,7 +829,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 t.last_tile_mode = 0;
                 if (tile_mode) {
                     // every read may survive with one candidate: (bases - (k-1) per read) * hashes * 1.125 + slack per bucket
-                    const uint64_t max_chunks = nc + ((t.leaf_cap + t.guard_cap) >> pfq::CHUNK_PAIRS_LOG2) + 2;
+                    const uint64_t max_chunks = nc + ((t.leaf_cap + t.guard_cap) >> chunk_log2) + 2;
                     uint64_t want = (uint64_t)((double)total_bytes * t.num_hashes * 1.13 * std::max(1.0, t.pairs_per_read)) +
                                     max_chunks * n_tiles * 544ull;
                     if (want * 4 > tile_budget) want = tile_budget / 4;
@@ -822,6 +851,13 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         ta.hp = t.hp;
                         ta.bits = t.d_bits.p;
                         ta.n_words = t.n_words;
+                        ta.chunk_log2 = chunk_log2;
+                        if (block_mode) {  // the "filter" of a bucket is its block's table: n_words * 64 bytes
+                            ta.blocks = 1;
+                            ta.bits = reinterpret_cast<const uint64_t *>(t.d_T.p);
+                            ta.n_words = t.n_words * 8;
+                            ta.failb = t.d_failb.p;
+                        }
                         ta.recs = recs;
                         ta.meta = t.d_meta.p;
                         ta.col_row = t.d_col_row.p;
@@ -865,7 +901,12 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         // spreads the chunks over passes that reuse it.  Their number is known on the device only; as
                         // many passes as the previous call needed are launched without waiting, and chunks of later
                         // passes (if any) are certified by the record kernel below — exact either way.
-                        const uint64_t n_passes = std::min<uint64_t>(std::max<uint64_t>(1, t.passes_hint), 256);  // (more: the record kernel takes the rest)
+                        uint64_t n_passes = std::min<uint64_t>(std::max<uint64_t>(1, t.passes_hint), 256);  // (more: the record kernel takes the rest)
+                        if (block_mode) {  // the fallback of block mode is slow: wait for the plan and launch every pass it needs
+                            HIP_TRY(hipMemcpyAsync(t.h_pair_cursor + 5, t.d_cursors.p + 2, 8, hipMemcpyDeviceToHost, st));
+                            HIP_TRY(hipStreamSynchronize(st));
+                            n_passes = ta.entry_cap ? std::min<uint64_t>(std::max<uint64_t>(1, (t.h_pair_cursor[5] + ta.entry_cap - 1) / ta.entry_cap), 256) : 1;
+                        }
                         for (uint64_t p = 0; p < n_passes; ++p) {
                             ta.pass = (uint32_t)p;
                             ta.bin_queue = t.d_binq.p + p;
@@ -904,6 +945,35 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                     HIP_TRY(hipEventRecord(ev[3], st));
                     HIP_TRY(hipEventRecord(ev[4], st));
                 }
+                if (block_mode) {
+                    // what the passes did not bin (overflows, no room, or no passes at all) is certified leaf by leaf against S
+                    a.S = t.d_S.p;
+                    a.col0 = 0;
+                    a.n_leaves = (uint32_t)std::min<size_t>(2048, nl);
+                    pfq::launch_block_fallback(a, t.d_sorted.p, off + nb, t.d_fail.p, t.d_failb.p, t.d_pair_chunk.p,
+                                               t.last_tile_mode ? t.d_chunks.p : nullptr, v.launched_passes, st);
+                    if (ev) HIP_TRY(hipEventRecord(ev[5], st));
+                    pfq::FinalizeArgs f{};
+                    f.hp = t.hp;
+                    f.off = d_off;
+                    f.sorted = t.d_sorted.p;
+                    f.bucket_off = off;
+                    f.sub_log2 = sub_log2;
+                    f.threshold = threshold;
+                    f.counts = t.d_counts.p;
+                    f.hit_pairs = a.hit_pairs;
+                    f.hit_cap = hit_cap;
+                    f.hit_cursor = t.d_cursors.p;
+                    f.stats = t.d_stats.p;
+                    f.failb = t.d_failb.p;
+                    f.c0 = 0;
+                    f.c1 = (uint32_t)nc;
+                    pfq::launch_finalize(f, st);
+                    if (ev) HIP_TRY(hipEventRecord(ev[6], st));
+                    t.last_block_mode = 1;
+                    if (t.last_tile_mode) t.last_tile_mode = 2;
+                    t.hint_counts = false;
+                } else {
                 if (v.only_flagged == 1 && counts_mode) {
                     // thresholds < 1: the list becomes every pair the tile passes left open (a k-mer missing, or not binned)
                     unsigned int *n_open = reinterpret_cast<unsigned int *>(t.d_cursors.p + 7);
@@ -954,6 +1024,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 f.guards = 0;
                 pfq::launch_finalize(f, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[6], st));
+                }
             } else {
                 PFQ_TRY(classify_groups(false));
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
@@ -963,6 +1034,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
         if (bucketed) {  // how many pair slots this call used, for the next call's sizing
             HIP_TRY(hipMemcpyAsync(t.h_pair_cursor, t.d_cursors.p + 1, 16, hipMemcpyDeviceToHost, st));  // pair cursor, bucket cursor
             HIP_TRY(hipMemcpyAsync(t.h_pair_cursor + 2, t.d_cursors.p + 6, 8, hipMemcpyDeviceToHost, st));  // pairs with a k-mer missing
+            HIP_TRY(hipMemcpyAsync(t.h_pair_cursor + 4, t.d_stats.p + pfq::ST_CANDIDATES, 8, hipMemcpyDeviceToHost, st));  // candidate leaves
             if (n_reads && nl)  // ... of how many sorted pairs (the pair cursor also counts partly used reservations)
                 HIP_TRY(hipMemcpyAsync(t.h_pair_cursor + 3, t.d_bucket.p + 2 * (nc << t.last_sub_log2), 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipEventRecord(t.hint_ev, st));

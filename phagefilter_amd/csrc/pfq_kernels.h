@@ -53,6 +53,7 @@ struct QueryArgs {
     uint32_t *long_list;         // thresholds < 1: reads of >= 256 k-mers, classified by a second launch (wider counters)
     unsigned int *n_long;
     uint32_t batch_tails;        // theta == 1 with records: last windows of <= TAIL_KMERS k-mers are left to k_tail_records
+    uint32_t block_pairs;        // 1 (DEFER, theta == 1, no guard columns): defer (read, block of 8 leaves | candidate mask << 24)
     // thresholds < 1: every deferred pair owns ceil(n/64) u64 words of k-mer miss bits.  k_classify only accounts for
     // them (per bucket, and against the buffer's capacity through per-wave reservations); k_bucket_scatter places them.
     uint32_t *bucket_words;            // [n_leaves << sub_log2] miss words per bucket, or nullptr (threshold 1)
@@ -124,6 +125,7 @@ struct FinalizeArgs {
     unsigned long long *hit_cursor;
     unsigned long long *stats;
     unsigned long long *n_dirty;  // thresholds < 1: += pairs with at least one k-mer missing (sizes the next call's certificate stage)
+    const uint8_t *failb;         // block mode (else nullptr): sorted pairs are (read, block | mask << 24), [pair][8] failure bytes
     // thresholds < 1 after LDS-tile passes with k-mer entries: a pair that was binned in a launched pass and never flagged
     // has its miss bits in its chunk's bitmap (kmiss); every other pair in its own miss words (written by k_verify_rec)
     const uint8_t *kmiss;         // nullptr: miss words only
@@ -140,7 +142,7 @@ constexpr uint32_t TILE_LOG2 = 20;                 // bits per tile = 128 KiB of
                                                    // 64 KiB tiles, two blocks per CU: bin 11.4 / test 5.9 ms vs 10.8 / 5.9)
 constexpr uint32_t CHUNK_PAIRS_LOG2 = 10;          // pairs per chunk: local pair id and tile offset share one u32 entry; a chunk
                                                    // is the work item of k_tile_bin (one block bins it alone)
-constexpr uint32_t MAX_TILES = 256;                // filters up to 2^27 bits take this path
+constexpr uint32_t MAX_TILES = 1024;               // tiles per filter the passes take (k_tile_bin keeps a bin per tile in LDS)
 // Thresholds < 1: the passes must tell WHICH k-mers are not contained, so an entry names a k-mer instead of a pair:
 // [round tag : 2][k-mer of the round : 11][offset in tile : 19] — k_tile_bin bins a chunk in rounds of <= 2^11 flattened
 // k-mers, the four entries of a 16-byte vector (runs are 16-byte aligned) carry the round's number in their tag bits, and
@@ -148,8 +150,16 @@ constexpr uint32_t MAX_TILES = 256;                // filters up to 2^27 bits ta
 constexpr uint32_t TILE_LOG2_COUNTS = 19;          // 64 KiB tiles (twice the tiles, 128-entry deeper bins than needed)
 constexpr uint32_t ROUND_KMERS_LOG2 = 11;          // flattened k-mers per round of k_tile_bin (= 2 windows x 16 waves)
 constexpr uint32_t MAX_ROUNDS = 256;               // rounds per chunk the tags can name; later pairs take the fallback
+// Reads that pass several related leaves (a phage database is full of strains): BLOCK MODE (threshold 1, trees without guard
+// columns).  A pair is (read, block of 8 consecutive leaf columns, mask of the candidate leaves in it); the block's "filter"
+// is a byte per Bloom bit index — bit j = that bit of leaf 8b + j — so ONE entry tests a probe for all candidate leaves of
+// the block: a read that passes 8 strains costs the probes of one pair instead of eight.  Entry = [mask:8][pair of the
+// chunk:7][byte offset in a 128 KiB tile:17]; chunks of <= 128 pairs.
+constexpr uint32_t TILE_LOG2_BLOCK = 17;           // 2^17 bit indices x 8 leaves = 128 KiB
+constexpr uint32_t CHUNK_PAIRS_LOG2_BLOCK = 7;
+constexpr uint32_t BLOCK_LEAVES_LOG2 = 3;
 struct ChunkDesc {
-    uint32_t row;      // filter row of the leaf
+    uint32_t row;      // filter row of the leaf (block mode: the block)
     uint32_t first;    // first sorted pair
     uint32_t n;        // pairs
     uint32_t cap;      // entries per (chunk, tile) bucket; 0: no room, the chunk's pairs take the fallback
@@ -186,6 +196,10 @@ struct TileArgs {
     uint32_t *flag_list;         // [flag_cap] their sorted-pair indices
     uint32_t flag_cap;
     const uint32_t *n_pairs_ptr;
+    // block mode (see TILE_LOG2_BLOCK)
+    uint32_t blocks;             // 1: pairs are (read, block | mask << 24), meta.w likewise; bits = block tables, n_words = bytes / 8 of one
+    uint32_t chunk_log2;         // pairs per chunk (CHUNK_PAIRS_LOG2, or CHUNK_PAIRS_LOG2_BLOCK)
+    uint8_t *failb;              // block mode: [sorted pair][8] a probed bit of that candidate leaf was 0
     // thresholds < 1 (entries name k-mers, see TILE_LOG2_COUNTS)
     float threshold;             // (which prefix of a read's k-mers is binned depends on it)
     uint32_t counts;             // 1: k-mer entries, 64 KiB tiles, miss bits; 0: pair entries, 128 KiB tiles, fail words
@@ -205,11 +219,18 @@ void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int block
 void launch_tail_records(const QueryArgs &a, int blocks, hipStream_t st);  // after launch_classify when a.batch_tails
 void launch_bucket_scan(const uint32_t *bucket_cnt, uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t n, hipStream_t st);
 // words_off / words_cur / miss_pos: thresholds < 1 (miss words of a bucket start at words_off[bucket]); else nullptr
+// col_row == nullptr: block mode (the key of a pair is the low 24 bits of its second word, which goes to meta.w whole)
 void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
                            const uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t sub_log2, uint2 *sorted, uint4 *meta,
                            const uint64_t *read_off, const uint32_t *col_row, const uint32_t *words_off, uint32_t *words_cur,
                            uint32_t *miss_pos, uint32_t kmer_size, const uint32_t *owner, uint32_t *owner_sorted, int blocks,
                            hipStream_t st);
+// block tables: T[b][i] = byte whose bit j is bit i of the filter of leaf column 8b + j (zero for columns past the last leaf)
+void launch_block_tables(const uint64_t *bits, uint64_t n_words, const uint32_t *d_col_row, uint32_t n_leaves, uint8_t *T, hipStream_t st);
+// block mode: flagged pairs (fail bit 1) certified leaf by leaf against the sliced matrix; then the counts / hits of all pairs
+// (chunks == nullptr: no tile passes ran, every pair is certified here)
+void launch_block_fallback(const QueryArgs &a, const uint2 *sorted, const uint32_t *n_pairs_ptr, const uint32_t *fail, uint8_t *failb,
+                           const uint32_t *pair_chunk, const ChunkDesc *chunks, uint32_t launched_passes, hipStream_t st);
 void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st);
 // list = the sorted pairs with a non-zero fail word, in order within runs; *n_out += their number (thresholds < 1 after tile passes)
 void launch_collect_open(const uint32_t *fail, const uint32_t *n_pairs_ptr, uint32_t *list, uint32_t cap, unsigned int *n_out, hipStream_t st);

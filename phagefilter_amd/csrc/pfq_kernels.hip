@@ -482,7 +482,9 @@ __device__ __forceinline__ bool has_batched_tail(uint64_t n) {
 // LPR_LOG2 (thresholds < 1): log2 of the lanes per read of the dense counting screen, rw = 4 << LPR_LOG2 (16, 32 or 64 row
 // words: a build per row width keeps the screen free of run-time shapes); 0: rows narrower than 16 words, per-read screen.
 // (the counting build is held to three waves per SIMD — 168 VGPRs; the allocator stops a few registers above on its own)
-template <bool DEFER, bool COUNTS, bool LONG = false, uint32_t LPR_LOG2 = 0>
+// BLOCKS (DEFER, theta == 1, no guard columns): survivors are deferred per block of 8 leaf columns — (read, block | mask of
+// the candidate leaves << 24) — see TILE_LOG2_BLOCK.
+template <bool DEFER, bool COUNTS, bool LONG = false, uint32_t LPR_LOG2 = 0, bool BLOCKS = false>
 __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0) ? 3 : 1) k_classify(QueryArgs a) {
     __shared__ BlockLds lds;
     __shared__ DenseLds<(DEFER && !LONG) || COUNTS> dlds;
@@ -542,9 +544,14 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0) ? 3 : 
             int src = __ffsll((unsigned long long)b) - 1;
             uint32_t wv = bcast_u32(live, src);
             uint32_t bit = (uint32_t)__ffs((int)wv) - 1u;
-            const uint32_t col = a.col0 + (uint32_t)src * 32u + bit;  // global column
-            if ((int)lane == src) live &= ~(1u << bit);
-            ++st_cand;
+            uint32_t mask8 = 1u;  // BLOCKS: the candidates among the 8 leaves of the block, taken together
+            if (BLOCKS) {
+                bit &= ~7u;
+                mask8 = (wv >> bit) & 0xffu;
+            }
+            const uint32_t col = a.col0 + (uint32_t)src * 32u + bit;  // global column (BLOCKS: the block's first)
+            if ((int)lane == src) live &= ~((BLOCKS ? 0xffu : 1u) << bit);
+            st_cand += BLOCKS ? (uint32_t)__popc(mask8) : 1u;
             // (guard columns — ancestors that are not provably supersets — of a deferred pair: k_expand_guards)
             const uint32_t miss_need = (COUNTS && a.bucket_words) ? (rc.n < (1ull << 37) ? (uint32_t)((rc.n + 63) >> 6) : 0xffffffffu) : 0u;
             if (DEFER && COUNTS && a.bucket_words && miss_left < miss_need && miss_need != 0xffffffffu) {  // wave-uniform
@@ -566,8 +573,9 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0) ? 3 : 
                 }
                 if (pair_used < PAIR_CHUNK) {
                     if (lane == 0) {
-                        const uint32_t bkt = (col << a.sub_log2) | ((uint32_t)r & ((1u << a.sub_log2) - 1u));
-                        a.pairs[pair_base + pair_used] = make_uint2((uint32_t)r, col);
+                        const uint32_t key = BLOCKS ? col >> BLOCK_LEAVES_LOG2 : col;
+                        const uint32_t bkt = (key << a.sub_log2) | ((uint32_t)r & ((1u << a.sub_log2) - 1u));
+                        a.pairs[pair_base + pair_used] = make_uint2((uint32_t)r, BLOCKS ? (key | (mask8 << 24)) : col);
                         atomicAdd(&a.bucket_cnt[bkt], 1u);
                         if (COUNTS && a.bucket_words) atomicAdd(&a.bucket_words[bkt], miss_need);
                     }
@@ -595,19 +603,23 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0) ? 3 : 
                 }
                 // no room left in the pair buffer: certify inline below (results stay exact)
             }
-            bool pass = verify_column(lds, wave, a, rc, col);
-            // ancestors that are not provably supersets must pass too (query.rs:119-141 visits children only with
-            // reads that passed the parent)
-            for (uint32_t g = a.guard_off[col]; pass && g < a.guard_off[col + 1]; ++g)
-                pass = verify_column(lds, wave, a, rc, a.guard_col[g]);
-            if (pass) {
-                ++st_hits;
-                st_bytes += rc.need * a.hp.num_hashes * 32ull;
-                if (lane == 0) {
-                    atomicAdd(&a.counts[col], 1ull);
-                    if (a.hit_pairs) {
-                        unsigned long long pos = atomicAdd(a.hit_cursor, 1ull);
-                        if (pos < a.hit_cap) a.hit_pairs[pos] = make_uint2((uint32_t)r, col);
+            for (uint32_t jb = 0; jb < (BLOCKS ? 8u : 1u); ++jb) {  // (BLOCKS: the candidates of the block one by one)
+                if (!((mask8 >> jb) & 1u)) continue;
+                const uint32_t cj = col + jb;
+                bool pass = verify_column(lds, wave, a, rc, cj);
+                // ancestors that are not provably supersets must pass too (query.rs:119-141 visits children only with
+                // reads that passed the parent)
+                for (uint32_t g = a.guard_off[cj]; pass && g < a.guard_off[cj + 1]; ++g)
+                    pass = verify_column(lds, wave, a, rc, a.guard_col[g]);
+                if (pass) {
+                    ++st_hits;
+                    st_bytes += rc.need * a.hp.num_hashes * 32ull;
+                    if (lane == 0) {
+                        atomicAdd(&a.counts[cj], 1ull);
+                        if (a.hit_pairs) {
+                            unsigned long long pos = atomicAdd(a.hit_cursor, 1ull);
+                            if (pos < a.hit_cap) a.hit_pairs[pos] = make_uint2((uint32_t)r, cj);
+                        }
                     }
                 }
             }
@@ -714,7 +726,8 @@ static void launch_classify_counts(const QueryArgs &a, dim3 g, dim3 b, hipStream
 void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int blocks, hipStream_t st) {
     dim3 g(blocks), b(256);
     if (!counts_mode) {
-        if (defer) hipLaunchKernelGGL((k_classify<true, false>), g, b, 0, st, a);
+        if (defer && a.block_pairs) hipLaunchKernelGGL((k_classify<true, false, false, 0, true>), g, b, 0, st, a);
+        else if (defer) hipLaunchKernelGGL((k_classify<true, false>), g, b, 0, st, a);
         else hipLaunchKernelGGL((k_classify<false, false>), g, b, 0, st, a);
         return;
     }
@@ -918,13 +931,14 @@ __global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, cons
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint2 p = pairs[i];
         if (p.y == 0xffffffffu) continue;  // voided slot of a partially used reservation
-        const uint32_t bkt = (p.y << sub_log2) | (p.x & ((1u << sub_log2) - 1u));
+        const uint32_t key = col_row ? p.y : (p.y & 0xffffffu);  // (block mode: block | mask << 24)
+        const uint32_t bkt = (key << sub_log2) | (p.x & ((1u << sub_log2) - 1u));
         uint32_t pos = off[bkt] + atomicAdd(&cur[bkt], 1u);
         sorted[pos] = p;
         if (owner) owner_sorted[pos] = owner[i];
         if (meta) {
             uint64_t o0 = read_off[p.x], L = read_off[p.x + 1] - o0;
-            meta[pos] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)L, col_row[p.y]);
+            meta[pos] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)L, col_row ? col_row[p.y] : p.y);
             if (miss_pos) {  // thresholds < 1: the pair's miss words, ceil(n/64) of them, inside its bucket's range
                 const uint32_t words = (uint32_t)((L - kmer_size + 1 + 63) >> 6);
                 miss_pos[pos] = words_off[bkt] + atomicAdd(&words_cur[bkt], words);
@@ -1221,7 +1235,8 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
     __shared__ uint32_t s_chunk0;
     const uint32_t c = blockIdx.x;
     const uint32_t lo = a.bucket_off[c << a.sub_log2], hi = a.bucket_off[(c + 1) << a.sub_log2];
-    const uint32_t n_ch = (hi - lo + (1u << CHUNK_PAIRS_LOG2) - 1u) >> CHUNK_PAIRS_LOG2;
+    const uint32_t cl = a.chunk_log2;
+    const uint32_t n_ch = (hi - lo + (1u << cl) - 1u) >> cl;
     if (threadIdx.x == 0) {
         s_chunk0 = n_ch ? atomicAdd(a.n_chunks, n_ch) : 0u;
         a.leaf_chunk0[c] = n_ch ? s_chunk0 : 0xffffffffu;
@@ -1229,7 +1244,7 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
     __syncthreads();
     const uint32_t chunk0 = s_chunk0;
     for (uint32_t ci = 0; ci < n_ch; ++ci) {
-        const uint32_t first = lo + (ci << CHUNK_PAIRS_LOG2), n = (hi - first) < (1u << CHUNK_PAIRS_LOG2) ? hi - first : (1u << CHUNK_PAIRS_LOG2);
+        const uint32_t first = lo + (ci << cl), n = (hi - first) < (1u << cl) ? hi - first : (1u << cl);
         if (threadIdx.x == 0) s_sum = 0;
         __syncthreads();
         unsigned long long kmers = 0;
@@ -1243,15 +1258,16 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
         if (lane_id() == 0 && kmers) atomicAdd(&s_sum, kmers);
         __syncthreads();
         if (threadIdx.x == 0 && chunk < a.max_chunks) {
-            // mean probes per tile + 12.5 % + slack (a uniform hash stays far below; anything beyond falls back) + the padding
-            // of k_tile_bin's runs (up to 3 entries per round: a round brings >= 96 probes per tile, or 32 pairs)
+            // mean probes per tile + 8 standard deviations of a Poisson count + slack (anything beyond falls back) + the
+            // padding of k_tile_bin's runs (up to 3 entries per round: a round brings >= 96 probes per tile, or 32 pairs)
             unsigned long long mean = (s_sum * a.hp.num_hashes + a.n_tiles - 1) / a.n_tiles;
-            uint32_t cap = (uint32_t)((mean + (mean >> 3) + (mean >> 5) + 512 + 3 * ((n + 31) / 32 + 1) + 31) & ~31ull);
+            const unsigned long long dev = (unsigned long long)(8.0f * sqrtf((float)mean)) + 64;
+            uint32_t cap = (uint32_t)((mean + dev + (mean >> 5) + 3 * ((n + 31) / 32 + 2) + 31) & ~31ull);
             unsigned long long need = (unsigned long long)cap * a.n_tiles;
             // (where the chunk's buckets go — pass and position in the reused buffer — is decided by k_tile_assign)
             const bool fits = need <= a.entry_cap;
             ChunkDesc dsc;
-            dsc.row = a.meta[first].w;
+            dsc.row = a.blocks ? (a.meta[first].w & 0xffffffu) : a.meta[first].w;
             dsc.first = first;
             dsc.n = n;
             dsc.cap = fits ? cap : 0u;   // a single chunk larger than the whole buffer: its pairs take the fallback
@@ -1381,31 +1397,37 @@ __device__ __forceinline__ void flag_fallback(const TileArgs &a, uint32_t e) {
 __device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, int src) {
     return ((unsigned long long)bcast_u32((uint32_t)(v >> 32), src) << 32) | bcast_u32((uint32_t)v, src);
 }
-template <uint32_t BIN_WAVES, uint32_t BIN_CAP, bool COUNTS>
+// MODE 0: (pair, offset) entries, 128 KiB tiles.  MODE 1 (thresholds < 1): k-mer entries.  MODE 2 (block mode): entries
+// [candidate mask:8][pair:7][byte offset:17] against the byte-per-index table of a block of 8 leaves.
+template <uint32_t BIN_WAVES, uint32_t BIN_CAP, uint32_t MODE>
 __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
+    constexpr bool COUNTS = MODE == 1, BLK = MODE == 2;
     // COUNTS (thresholds < 1): an entry is [round tag:2][flattened k-mer of the round:11][offset in a 64 KiB tile:19]; the
     // tags are ORed in at flush time (position in the 16-byte vector -> two bits of the round's number), runs are padded
     // with copies of their last entry (testing a probe twice changes nothing), and per round the chunk position of its
     // first k-mer goes to round_k0, per pair the position of its first k-mer to pair_kpos.
-    constexpr uint32_t TL = COUNTS ? TILE_LOG2_COUNTS : TILE_LOG2;
+    constexpr uint32_t TL = COUNTS ? TILE_LOG2_COUNTS : (BLK ? TILE_LOG2_BLOCK : TILE_LOG2);
     constexpr uint32_t BIN_STRIDE = BIN_CAP + 4;  // rows stay 16-byte aligned; room for the padding of a full bin
     constexpr uint32_t WPI = 2;                    // windows per wave and iteration
-    constexpr uint32_t DUMMY = MAX_TILES;          // counters MAX_TILES .. MAX_TILES + 63: where lanes without a probe count
-    extern __shared__ uint32_t s_dyn[];            // cnt[MAX_TILES + 64], fill[MAX_TILES], bins[n_tiles][BIN_STRIDE]
+    const uint32_t NT = (a.n_tiles + 63u) & ~63u;  // tiles, rounded up
+    const uint32_t DUMMY = NT;                     // counters NT .. NT + 63: where lanes without a probe count
+    extern __shared__ uint32_t s_dyn[];            // cnt[NT + 64], fill[NT], bins[n_tiles][BIN_STRIDE]
     __shared__ uint32_t s_chunk;
-    uint32_t *cnt = s_dyn, *fillp = s_dyn + MAX_TILES + 64, *bins = fillp + MAX_TILES;
+    uint32_t *cnt = s_dyn, *fillp = s_dyn + NT + 64, *bins = fillp + NT;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t d = (uint32_t)a.hp.nbits, dw = d - (uint32_t)a.hp.w64, k = a.hp.k, nh = a.hp.num_hashes;
     const uint32_t n_chunks = *a.n_chunks < a.max_chunks ? *a.n_chunks : a.max_chunks;
-    uint32_t KB = (uint32_t)(((uint64_t)(BIN_CAP - BIN_CAP / 4) * a.n_tiles) / nh);
+    // k-mers per round: the bins fill to 3/4 on average (shallow bins of many tiles — block mode — to 1/2: an overflow costs
+    // the round's pairs the fallback, and 30 +- 5.5 entries must stay below 60)
+    uint32_t KB = (uint32_t)(((uint64_t)(BIN_CAP < 128 ? BIN_CAP / 2 : BIN_CAP - BIN_CAP / 4) * a.n_tiles) / nh);
     if (KB > WPI * BIN_WAVES * WIN_KMERS) KB = WPI * BIN_WAVES * WIN_KMERS;
     if (COUNTS && KB > (1u << ROUND_KMERS_LOG2)) KB = 1u << ROUND_KMERS_LOG2;
     if (KB == 0) KB = 1;
-    for (uint32_t t = threadIdx.x; t < MAX_TILES + 64; t += blockDim.x) cnt[t] = 0;
+    for (uint32_t t = threadIdx.x; t < NT + 64; t += blockDim.x) cnt[t] = 0;
     while (true) {
         __syncthreads();  // everybody is done with the previous chunk
         if (threadIdx.x == 0) s_chunk = atomicAdd(a.bin_queue, 1u);
-        for (uint32_t t = threadIdx.x; t < MAX_TILES; t += blockDim.x) fillp[t] = 0;
+        for (uint32_t t = threadIdx.x; t < NT; t += blockDim.x) fillp[t] = 0;
         __syncthreads();
         const uint32_t c = s_chunk;
         if (c >= n_chunks) break;
@@ -1422,6 +1444,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
         // sums of their k-mer counts, qb = record index of flattened k-mer 0 of the lane's pair.
         struct Round {
             uint32_t p, P, K, incl, start;  // start: flattened index of the first k-mer of the lane's pair
+            uint32_t mask;                   // BLK: candidate mask of the lane's pair, in place (bits 24..31)
             unsigned long long koff, qb;
             bool partial;
         };
@@ -1441,6 +1464,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
             }
             r.incl = incl;
             r.start = incl - n_l;
+            r.mask = m.w & 0xff000000u;
             r.P = (uint32_t)__popcll(ballot64(cand && incl <= KB));  // incl is monotone: a prefix of the candidates
             r.partial = r.P == 0 && p < dsc.n;  // the first pair alone exceeds the budget: the next KB k-mers of it
             if (r.partial) {
@@ -1464,17 +1488,20 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                 if (j0 >= r.P) j0 = r.P ? r.P - 1 : 0;  // (window past the end: no valid lane)
                 uint32_t j = j0;
                 unsigned long long qb = bcast_u64(r.qb, (int)j0);
+                uint32_t mk = BLK ? bcast_u32(r.mask, (int)j0) : 0u;
                 for (uint32_t t = j0; t + 1 < r.P; ++t) {
                     const uint32_t e = bcast_u32(r.incl, (int)t);
                     if (e > f0 + 63u) break;
                     const unsigned long long qn = bcast_u64(r.qb, (int)t + 1);
+                    const uint32_t mn = BLK ? bcast_u32(r.mask, (int)t + 1) : 0u;
                     if (f >= e) {
                         j = t + 1;
                         qb = qn;
+                        mk = mn;
                     }
                 }
                 rec[u] = valid[u] ? a.recs[qb + f] : make_uint4(0, 0, 0, 0);  // (no k-mer: every index 0, see `put`)
-                local[u] = (COUNTS ? f : r.p + j) << TL;
+                local[u] = ((COUNTS ? f : r.p + j) << TL) | mk;
             }
         };
         // Software pipeline over the rounds: while round r is binned, the records of round r + 1 and the pair metadata of
@@ -1571,13 +1598,13 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                 const uint32_t cn = have ? cnt[t] : 0u, pos = have ? fillp[t] : 0u;
                 const uint32_t cc = cn < BIN_CAP ? cn : BIN_CAP, c4 = (cc + 3u) & ~3u;
                 uint32_t *row = bins + t * BIN_STRIDE;
-                if (sl < c4 - cc) row[cc + sl] = COUNTS ? row[cc - 1u] : ENTRY_PAD;  // (c4 > cc only when cc >= 1)
+                if (sl < c4 - cc) row[cc + sl] = (COUNTS || BLK) ? row[cc - 1u] : ENTRY_PAD;  // (c4 > cc only when cc >= 1; a mask-carrying entry could equal ENTRY_PAD)
                 __builtin_amdgcn_wave_barrier();
                 // what fits is written (k_tile_test reads min(fill, cap) entries: every slot below cap must hold an entry
                 // or padding); the pairs whose probes are dropped — bucket full — take the fallback
                 const uint32_t room = pos < dsc.cap ? dsc.cap - pos : 0u, wr = c4 < room ? c4 : room;
                 uint32_t *dst = bucket0 + (uint64_t)(have ? t : 0u) * dsc.cap + pos;
-                constexpr uint32_t FB = 5;  // 16-byte reads in flight per lane: two batches cover a full bin (516 entries / 64)
+                constexpr uint32_t FB = BIN_CAP < 128 ? 2 : 5;  // 16-byte reads in flight per lane: two batches cover a full bin (516 entries / 64)
                 const uint32_t wr_eff = (a.debug & 1u) ? 0u : wr;
                 for (uint32_t i0 = sl * 4u; i0 < wr; i0 += STEP * FB) {
                     uint4 v[FB];
@@ -1601,7 +1628,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                         if (i0 + u * STEP < wr_eff) *reinterpret_cast<uint4 *>(dst + i0 + u * STEP) = v[u];
                 }
                 if (!COUNTS)
-                    for (uint32_t i = wr + sl; i < cc; i += LPT) flag_fallback(a, dsc.first + (row[i] >> TL));
+                    for (uint32_t i = wr + sl; i < cc; i += LPT) flag_fallback(a, dsc.first + ((BLK ? row[i] & 0xffffffu : row[i]) >> TL));
                 if (cn > BIN_CAP || (COUNTS && wr < cc)) {  // the LDS bin (or, with k-mer entries, the bucket) overflowed: whose probes were lost is unknown
                     for (uint32_t i = sl; i < flush_P; i += LPT) flag_fallback(a, dsc.first + flush_p + i);
                 }
@@ -1623,15 +1650,18 @@ template <uint32_t W, uint32_t CAP>
 static void launch_tile_bin_shape(const TileArgs &a, int blocks, size_t lds, hipStream_t st) {
     static bool attr_set = false;  // (per instantiation)
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    if (a.counts) hipLaunchKernelGGL((k_tile_bin<W, CAP, true>), dim3(blocks), dim3(W * 64), lds, st, a);
-    else hipLaunchKernelGGL((k_tile_bin<W, CAP, false>), dim3(blocks), dim3(W * 64), lds, st, a);
+    if (a.counts) hipLaunchKernelGGL((k_tile_bin<W, CAP, 1>), dim3(blocks), dim3(W * 64), lds, st, a);
+    else if (a.blocks) hipLaunchKernelGGL((k_tile_bin<W, CAP, 2>), dim3(blocks), dim3(W * 64), lds, st, a);
+    else hipLaunchKernelGGL((k_tile_bin<W, CAP, 0>), dim3(blocks), dim3(W * 64), lds, st, a);
 }
 void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
-    auto lds_of = [&](size_t cap) { return (2 * MAX_TILES + 64 + (size_t)a.n_tiles * (cap + 4)) * 4; };
+    const size_t nt = (a.n_tiles + 63u) & ~63u;
+    auto lds_of = [&](size_t cap) { return (2 * nt + 64 + (size_t)a.n_tiles * (cap + 4)) * 4; };
     if (a.bin_shape == 3 && lds_of(256) <= 74 * 1024) {  // experiment: two 8-wave blocks per CU
         launch_tile_bin_shape<8, 256>(a, blocks, lds_of(256), st);
     } else if (lds_of(2048) <= 148 * 1024 && a.bin_shape == 0) {  // few tiles (small filters): deeper bins, longer rounds
@@ -1642,8 +1672,10 @@ void launch_tile_bin(const TileArgs &a, int blocks, hipStream_t st) {
         launch_tile_bin_shape<16, 512>(a, (blocks + 1) / 2, lds_of(512), st);
     } else if (lds_of(256) <= 148 * 1024 && a.bin_shape != 1) {
         launch_tile_bin_shape<16, 256>(a, (blocks + 1) / 2, lds_of(256), st);
-    } else {
+    } else if (lds_of(128) <= 148 * 1024) {
         launch_tile_bin_shape<8, 128>(a, blocks, lds_of(128), st);
+    } else {  // several hundred tiles (block mode of large filters): shallow bins
+        launch_tile_bin_shape<16, 60>(a, (blocks + 1) / 2, lds_of(60), st);
     }
 }
 
@@ -1657,18 +1689,26 @@ constexpr uint32_t TEST_GROUP = 32;  // chunks of a leaf whose buckets are strea
 // COUNTS (thresholds < 1): an entry names a k-mer of its round (see TILE_LOG2_COUNTS); a probed bit that is 0 sets the
 // k-mer's byte in its chunk's miss array — position round_k0[chunk][round] + k-mer of the round, the table rows of the
 // group's chunks staged in LDS (and, like the tile, fetched while the previous task streams).
-template <bool COUNTS>
+// MODE 2 (block mode): the tile is 2^17 BYTES of the block's table, bit j of a byte = that Bloom bit of leaf 8b + j; an entry
+// carries the mask of the pair's candidate leaves; a candidate whose bit is 0 gets its failure byte set (plain stores: one
+// byte per (pair, leaf)), reported once per block and task through the LDS bitmap.
+template <uint32_t MODE>
 __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
-    constexpr uint32_t TL = COUNTS ? TILE_LOG2_COUNTS : TILE_LOG2;
-    constexpr uint32_t TV = (1u << (TL - 5)) / 2048u;  // 8-byte loads per thread and tile
+    constexpr bool COUNTS = MODE == 1, BLK = MODE == 2;
+    constexpr uint32_t TL = COUNTS ? TILE_LOG2_COUNTS : (BLK ? TILE_LOG2_BLOCK : TILE_LOG2);
+    constexpr uint32_t TILE_BYTES = BLK ? (1u << TL) : (1u << (TL - 3));
+    constexpr uint32_t TV = TILE_BYTES / 8192u;        // 8-byte loads per thread and tile
+    constexpr uint32_t CL = BLK ? CHUNK_PAIRS_LOG2_BLOCK : CHUNK_PAIRS_LOG2;  // pairs per chunk (LDS bitmap of reported failures)
     constexpr uint32_t RK = COUNTS ? MAX_ROUNDS : 1u;
     extern __shared__ uint32_t s_tile[];  // 2^TL bits
     __shared__ uint32_t s_pref[2][TEST_GROUP + 1], s_first[2][TEST_GROUP], s_misc[2][2], s_kbase[2][TEST_GROUP];
-    __shared__ uint32_t s_failed[COUNTS ? 1 : (TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5))];  // pairs of the group this block already reported
+    // failures this block already reported: a bit per pair of the group (MODE 0), per (pair, leaf of the block) (MODE 2)
+    __shared__ uint32_t s_failed[COUNTS ? 1 : (BLK ? (TEST_GROUP << (CL - 2)) : (TEST_GROUP << (CL - 5)))];
+    constexpr uint32_t N_FAILED = COUNTS ? 0 : (BLK ? (TEST_GROUP << (CL - 2)) : (TEST_GROUP << (CL - 5)));
     __shared__ uint32_t s_rk0[COUNTS ? TEST_GROUP : 1][RK];                               // round_k0 rows of the group's chunks
     __shared__ unsigned long long s_base[2][TEST_GROUP];
-    const uint32_t tile_words = 1u << (TL - 5);
-    const uint64_t n_words32 = a.n_words * 2;
+    const uint32_t tile_words = TILE_BYTES / 4u;
+    const uint64_t n_words32 = a.n_words * 2;  // (block mode: n_words = bytes / 8 of one block's table)
     const uint64_t n_tasks = (uint64_t)a.n_leaves * a.n_tiles;
     const uint32_t n_chunks = *a.n_chunks < a.max_chunks ? *a.n_chunks : a.max_chunks;
     // next task of this block at or after `task` whose column has pairs at all (block-uniform)
@@ -1705,7 +1745,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     // the column's tile: words [t * tile_words, ...) of its filter row (zero beyond the filter's end); filter rows are only
     // 8-byte aligned: 8-byte loads, all of a thread in flight
     auto tile_loads = [&](uint32_t leaf, uint32_t t, uint2 (&v)[TV]) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)a.col_row[leaf] * a.n_words);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)(BLK ? leaf : a.col_row[leaf]) * a.n_words);
         const uint64_t w0 = (uint64_t)t * tile_words;
 #pragma unroll
         for (uint32_t u = 0; u < TV; ++u) {
@@ -1717,7 +1757,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
 #pragma unroll
         for (uint32_t u = 0; u < TV; ++u) *reinterpret_cast<uint2 *>(s_tile + threadIdx.x * 2 + u * 2048u) = v[u];
         if (!COUNTS)
-            for (uint32_t i = threadIdx.x; i < (TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)); i += blockDim.x) s_failed[i] = 0;
+            for (uint32_t i = threadIdx.x; i < N_FAILED; i += blockDim.x) s_failed[i] = 0;
     };
     // COUNTS: the round_k0 rows of the 32 chunks from g0 on: 32 threads per chunk, 8 rounds per thread (rounds the chunk
     // did not have — and chunks of other columns — are never looked up)
@@ -1757,7 +1797,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
                     while (v >= s_pref[buf][ci + 1]) ++ci;
                     en[u] = *reinterpret_cast<const uint4 *>(a.entries + s_base[buf][ci] + (v - s_pref[buf][ci]));
                     first[u] = s_first[buf][ci];
-                    cidx[u] = COUNTS ? ci : ci << CHUNK_PAIRS_LOG2;
+                    cidx[u] = COUNTS ? ci : ci << CL;
                 }
             }
 #pragma unroll
@@ -1780,6 +1820,18 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
                             // a plain byte store: idempotent, no read-modify-write (device-scope atomics are performed at
                             // the memory side on this part — 2.7 G/s when a k-mer over a sequencing error fails in ten tiles)
                             a.kmiss[(uint64_t)wb + kb + ((ev[c] >> TL) & ((1u << ROUND_KMERS_LOG2) - 1u))] = 1;
+                        }
+                    }
+                } else if (BLK) {
+                    if (!have[u]) continue;
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; ++c) {
+                        const uint32_t off = ev[c] & ((1u << TL) - 1u);
+                        const uint32_t bad = (ev[c] >> 24) & ~(uint32_t)reinterpret_cast<const uint8_t *>(s_tile)[off];
+                        if (bad) {  // candidates whose bit is 0; only what this block has not reported yet goes to memory
+                            const uint32_t lp = (ev[c] >> TL) & ((1u << CL) - 1u), fb = cidx[u] + lp, sh = 8u * (fb & 3u);
+                            const uint32_t fresh = bad & ~(atomicOr(&s_failed[fb >> 2], bad << sh) >> sh);
+                            for (uint32_t m = fresh; m; m &= m - 1u) a.failb[((uint64_t)(first[u] + lp) << 3) + (uint32_t)__ffs((int)m) - 1u] = 1;
                         }
                     }
                 } else {
@@ -1833,7 +1885,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
                 rk_loads(g0, rk);
                 rk_store(rk);
             } else {
-                for (uint32_t i = threadIdx.x; i < (TEST_GROUP << (CHUNK_PAIRS_LOG2 - 5)); i += blockDim.x) s_failed[i] = 0;
+                for (uint32_t i = threadIdx.x; i < N_FAILED; i += blockDim.x) s_failed[i] = 0;
             }
             __syncthreads();
         }
@@ -1850,13 +1902,16 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
 void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        // (static LDS of the COUNTS build: the 32 KiB of round_k0 rows; static + dynamic must stay within the CU's 160 KiB)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << (TILE_LOG2_COUNTS - 3));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        // (static LDS of the k-mer-entry build: the 32 KiB of round_k0 rows; static + dynamic must stay within the CU's 160 KiB)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << (TILE_LOG2_COUNTS - 3));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    if (a.counts) hipLaunchKernelGGL(k_tile_test<true>, dim3((blocks + 1) / 2), dim3(1024), (size_t)(1u << (TILE_LOG2_COUNTS - 3)), st, a);
-    else hipLaunchKernelGGL(k_tile_test<false>, dim3((blocks + 1) / 2), dim3(1024), (size_t)(1u << (TILE_LOG2 - 3)), st, a);
+    const dim3 g((blocks + 1) / 2), b(1024);
+    if (a.counts) hipLaunchKernelGGL(k_tile_test<1>, g, b, (size_t)(1u << (TILE_LOG2_COUNTS - 3)), st, a);
+    else if (a.blocks) hipLaunchKernelGGL(k_tile_test<2>, g, b, (size_t)(1u << TILE_LOG2_BLOCK), st, a);
+    else hipLaunchKernelGGL(k_tile_test<0>, g, b, (size_t)(1u << (TILE_LOG2 - 3)), st, a);
 }
 
 // Thresholds < 1 after the tile passes: the compact list of the pairs whose fail word is non-zero (a probe found 0, or the
@@ -1907,9 +1962,118 @@ void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st)
     else hipLaunchKernelGGL(k_verify, dim3(blocks), dim3(256), 0, st, a);
 }
 
+// Block tables (block mode): T[b][i] = byte whose bit j is bit i of the filter of leaf column 8b + j.  A wave takes one
+// 64-bit word of the 8 filters at a time: every lane reads the 8 words (one transaction each), lane i assembles byte i.
+__global__ void __launch_bounds__(256) k_block_tables(const uint64_t *bits, uint64_t n_words, const uint32_t *col_row, uint32_t n_leaves, uint8_t *T) {
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, b = blockIdx.y;
+    uint8_t *dst = T + (uint64_t)b * n_words * 64;
+    const uint64_t *src[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) src[j] = (8u * b + j < n_leaves) ? bits + (uint64_t)col_row[8u * b + j] * n_words : nullptr;
+    for (uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; w < n_words; w += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
+        uint32_t byte = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint64_t v = src[j] ? src[j][w] : 0ull;
+            byte |= (uint32_t)((v >> lane) & 1ull) << j;
+        }
+        dst[w * 64 + lane] = (uint8_t)byte;
+    }
+}
+void launch_block_tables(const uint64_t *bits, uint64_t n_words, const uint32_t *d_col_row, uint32_t n_leaves, uint8_t *T, hipStream_t st) {
+    if (!n_leaves) return;
+    uint64_t bx = (n_words + 3) / 4;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_block_tables, dim3((uint32_t)bx, (n_leaves + 7) / 8), dim3(256), 0, st, bits, n_words, d_col_row, n_leaves, T);
+}
+
+// Block mode: the pairs k_tile_bin could not bin (fail bit 1: a bin or a bucket overflowing, no room for the buckets) are
+// certified here, candidate leaf by candidate leaf, against the sliced matrix (exact, slow: one line gather per probe).
+__global__ void __launch_bounds__(256) k_block_fallback(QueryArgs a, const uint2 *sorted, const uint32_t *n_pairs_ptr, const uint32_t *fail, uint8_t *failb,
+                                                        const uint32_t *pair_chunk, const ChunkDesc *chunks, uint32_t launched_passes) {
+    __shared__ BlockLds lds;
+    fill_complement(lds.comp);
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, n_pairs = *n_pairs_ptr;
+    const uint64_t gw = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave, nw = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (uint64_t e0 = gw * 64u; e0 < n_pairs; e0 += nw * 64u) {
+        const uint64_t e = e0 + lane;
+        bool flagged = e < n_pairs && (fail[e] & 2u);
+        if (e < n_pairs && !flagged) {  // not binned at all: no tile passes (chunks == nullptr), or its chunk's pass was not launched
+            if (!chunks) flagged = true;
+            else {
+                const uint32_t c = pair_chunk[e];
+                flagged = c == 0xffffffffu || chunks[c].pass >= launched_passes;
+            }
+        }
+        uint2 p = make_uint2(0, 0);
+        if (flagged) p = sorted[e];
+        uint64_t todo = ballot64(flagged);
+        while (todo) {
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t r = bcast_u32(p.x, src), y = bcast_u32(p.y, src);
+            const uint64_t o0 = a.off[r], L = a.off[r + 1] - o0;
+            ReadCtx rc;
+            rc.read = a.seq + o0;
+            rc.n = L - a.hp.k + 1;  // deferred reads have k-mers and need == n
+            rc.need = need_kmers(a.threshold, rc.n);
+            rc.maxmiss = rc.n - rc.need;
+            for (uint32_t j = 0; j < 8; ++j) {
+                if (!((y >> (24 + j)) & 1u)) continue;
+                const bool pass = verify_column(lds, wave, a, rc, ((y & 0xffffffu) << BLOCK_LEAVES_LOG2) + j);
+                if (!pass && lane == 0) failb[((e0 + (uint32_t)src) << 3) + j] = 1;
+            }
+        }
+    }
+}
+void launch_block_fallback(const QueryArgs &a, const uint2 *sorted, const uint32_t *n_pairs_ptr, const uint32_t *fail, uint8_t *failb,
+                           const uint32_t *pair_chunk, const ChunkDesc *chunks, uint32_t launched_passes, hipStream_t st) {
+    hipLaunchKernelGGL(k_block_fallback, dim3(1024), dim3(256), 0, st, a, sorted, n_pairs_ptr, fail, failb, pair_chunk, chunks, launched_passes);
+}
+
 // One block per leaf bucket: pairs that no slice failed are hits (mapped_reads += |pass|, query.rs:143).
 __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
     __shared__ unsigned long long s_cnt, s_bytes;
+    if (a.failb) {  // block mode: bucket = block of 8 leaves; a candidate leaf of a pair hits unless one of its probes failed
+        __shared__ unsigned int s_leaf[8];
+        for (uint32_t c = a.c0 + blockIdx.x; c < a.c1; c += gridDim.x) {
+            if (threadIdx.x < 8) s_leaf[threadIdx.x] = 0;
+            if (threadIdx.x == 0) s_bytes = 0;
+            __syncthreads();
+            unsigned long long bytes = 0;
+            for (uint32_t e = a.bucket_off[c << a.sub_log2] + threadIdx.x; e < a.bucket_off[(c + 1) << a.sub_log2]; e += blockDim.x) {
+                const uint2 p = a.sorted[e];
+                const uint2 fb = *reinterpret_cast<const uint2 *>(a.failb + ((uint64_t)e << 3));
+                uint32_t failed = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    failed |= ((fb.x >> (8u * j)) & 0xffu) ? 1u << j : 0u;
+                    failed |= ((fb.y >> (8u * j)) & 0xffu) ? 16u << j : 0u;
+                }
+                const uint64_t o0 = a.off[p.x], L = a.off[p.x + 1] - o0, n = L - a.hp.k + 1;
+                for (uint32_t m = (p.y >> 24) & ~failed; m; m &= m - 1u) {
+                    const uint32_t j = (uint32_t)__ffs((int)m) - 1u;
+                    atomicAdd(&s_leaf[j], 1u);
+                    bytes += n * a.hp.num_hashes * 32ull;
+                    if (a.hit_pairs) {
+                        unsigned long long pos = atomicAdd(a.hit_cursor, 1ull);
+                        if (pos < a.hit_cap) a.hit_pairs[pos] = make_uint2(p.x, ((p.y & 0xffffffu) << BLOCK_LEAVES_LOG2) + j);
+                    }
+                }
+            }
+            for (int d = 32; d > 0; d >>= 1) bytes += __shfl_down(bytes, d);
+            if (lane_id() == 0 && bytes) atomicAdd(&s_bytes, bytes);
+            __syncthreads();
+            if (threadIdx.x < 8 && s_leaf[threadIdx.x]) {
+                atomicAdd(&a.counts[(c << BLOCK_LEAVES_LOG2) + threadIdx.x], (unsigned long long)s_leaf[threadIdx.x]);
+                atomicAdd(&a.stats[ST_HITS], (unsigned long long)s_leaf[threadIdx.x]);
+            }
+            if (threadIdx.x == 0 && s_bytes) atomicAdd(&a.stats[ST_ALG_BYTES], s_bytes);
+            __syncthreads();
+        }
+        return;
+    }
     for (uint32_t c = a.c0 + blockIdx.x; c < a.c1; c += gridDim.x) {
         if (threadIdx.x == 0) { s_cnt = 0; s_bytes = 0; }
         __syncthreads();

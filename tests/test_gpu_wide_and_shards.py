@@ -273,9 +273,43 @@ def test_family_workload_parity_300k_reads(gpu):
             offs, leaves = gt.query_packed(seq, off, thr, want_hits=True)
             st = gt.last_stats()
             assert st.path == 1
+            # at threshold 1 the calls after the first know that reads pass several leaves: block mode
+            assert st.tile_mode == (2 if thr == 1.0 and call > 0 else 1), (thr, call, st.tile_mode)
             assert gt.get_leaf_counts() == ot.leaf_counts(), (thr, call)
             got = np.stack([np.repeat(np.arange(n_reads), np.diff(offs).astype(np.int64)), leaves.astype(np.int64)], 1)
             assert np.array_equal(got, want), (thr, call)
+    gt.close()
+
+
+@pytest.mark.parametrize("n_genomes,k,nbits,h", [(13, 21, 100003, 5), (64, 21, 65536, 6), (130, 16, 262144, 10), (2300, 21, 65521, 4)])
+def test_block_mode_forced(gpu, n_genomes, k, nbits, h):
+    """Block mode (pairs = read x block of 8 leaves x candidate mask, one entry tests a probe for all candidates): forced with
+    PFQ_BLOCK=1 on trees whose leaf count is no multiple of 8, with twins and near-twins inside and across blocks, through
+    one and several column groups; also with too little room for the probe buckets (several passes; chunks larger than the
+    buffer, which the fallback certifies against the sliced matrix) and with none at all."""
+    genomes = [rand_dna(int(RNG.integers(200, 500))) for _ in range(n_genomes)]
+    genomes[1] = genomes[0]                                          # twins in one block
+    genomes[9 % n_genomes] = genomes[2]                              # twins in different blocks
+    genomes[5] = genomes[4][:180] + genomes[5][180:]                 # near-twins
+    genomes[n_genomes - 1] = genomes[3]
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    gt = gpu_tree(genomes, ids, k, nbits, h)
+    reads = make_reads(genomes, 600, 200, 150, k) + make_reads(genomes, 10, 5, 420, k) + make_reads(genomes, 20, 5, k + 3, k)
+    reads += [genomes[0][:150], genomes[2][10:170], genomes[4][:150], genomes[3][:k], b"ACGT", b""]
+    gt.set_option("PFQ_BLOCK", "1")
+    for env in ({}, {"PFQ_TILE_ENTRIES": "200000"}, {"PFQ_TILE_ENTRIES": "3000"}, {"PFQ_TILE_GB": "0"}):
+        for key, val in env.items():
+            gt.set_option(key, val)
+        try:
+            st = check_query(gt, ot, reads, 1.0, path=1)
+            assert st.path == 1 and st.tile_mode == 2, (env, st.tile_mode)
+        finally:
+            for key in env:
+                gt.set_option(key, None)
+    # thresholds below 1 keep the pair pipeline; PFQ_BLOCK=0 forbids block mode
+    assert check_query(gt, ot, reads, 0.5, path=1).tile_mode == 1
+    gt.set_option("PFQ_BLOCK", "0")
+    assert check_query(gt, ot, reads, 1.0, path=1).tile_mode == 1
     gt.close()
 
 
