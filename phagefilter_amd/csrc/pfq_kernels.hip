@@ -1699,14 +1699,15 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     constexpr uint32_t TILE_BYTES = BLK ? (1u << TL) : (1u << (TL - 3));
     constexpr uint32_t TV = TILE_BYTES / 8192u;        // 8-byte loads per thread and tile
     constexpr uint32_t CL = BLK ? CHUNK_PAIRS_LOG2_BLOCK : CHUNK_PAIRS_LOG2;  // pairs per chunk (LDS bitmap of reported failures)
+    constexpr uint32_t TG = BLK ? 64 : TEST_GROUP;  // chunks per unit (block mode: chunks of 128 pairs, a unit should still bring >= 16 k entries)
     constexpr uint32_t RK = COUNTS ? MAX_ROUNDS : 1u;
     extern __shared__ uint32_t s_tile[];  // 2^TL bits
-    __shared__ uint32_t s_pref[2][TEST_GROUP + 1], s_first[2][TEST_GROUP], s_misc[2][2], s_kbase[2][TEST_GROUP];
+    __shared__ uint32_t s_pref[2][TG + 1], s_first[2][TG], s_misc[2][2], s_kbase[2][TG];
     // failures this block already reported: a bit per pair of the group (MODE 0), per (pair, leaf of the block) (MODE 2)
-    __shared__ uint32_t s_failed[COUNTS ? 1 : (BLK ? (TEST_GROUP << (CL - 2)) : (TEST_GROUP << (CL - 5)))];
-    constexpr uint32_t N_FAILED = COUNTS ? 0 : (BLK ? (TEST_GROUP << (CL - 2)) : (TEST_GROUP << (CL - 5)));
-    __shared__ uint32_t s_rk0[COUNTS ? TEST_GROUP : 1][RK];                               // round_k0 rows of the group's chunks
-    __shared__ unsigned long long s_base[2][TEST_GROUP];
+    __shared__ uint32_t s_failed[COUNTS ? 1 : (BLK ? (TG << (CL - 2)) : (TG << (CL - 5)))];
+    constexpr uint32_t N_FAILED = COUNTS ? 0 : (BLK ? (TG << (CL - 2)) : (TG << (CL - 5)));
+    __shared__ uint32_t s_rk0[COUNTS ? TG : 1][RK];                               // round_k0 rows of the group's chunks
+    __shared__ unsigned long long s_base[2][TG];
     const uint32_t tile_words = TILE_BYTES / 4u;
     const uint64_t n_words32 = a.n_words * 2;  // (block mode: n_words = bytes / 8 of one block's table)
     const uint64_t n_tasks = (uint64_t)a.n_leaves * a.n_tiles;
@@ -1721,16 +1722,16 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     auto describe = [&](uint32_t buf, uint32_t leaf, uint32_t t, uint32_t g0) {  // threads 0..63
         const uint32_t i = threadIdx.x, c = g0 + i;
         ChunkDesc dsc{};
-        const bool mine = i < TEST_GROUP && c < n_chunks && (dsc = a.chunks[c], dsc.leaf == leaf);
+        const bool mine = i < TG && c < n_chunks && (dsc = a.chunks[c], dsc.leaf == leaf);
         const bool usable = mine && dsc.cap != 0 && dsc.pass == a.pass;
         uint32_t fill = usable ? a.gfill[(uint64_t)c * a.n_tiles + t] : 0u;
         if (fill > dsc.cap) fill = dsc.cap;
         uint32_t incl = fill;
-        for (uint32_t sft = 1; sft < TEST_GROUP; sft <<= 1) {
+        for (uint32_t sft = 1; sft < TG; sft <<= 1) {
             const uint32_t o = (uint32_t)__shfl_up((int)incl, (int)sft);
             if (i >= sft) incl += o;
         }
-        if (i < TEST_GROUP) {
+        if (i < TG) {
             s_pref[buf][i + 1] = incl;
             s_first[buf][i] = dsc.first;
             s_kbase[buf][i] = dsc.kbase;
@@ -1772,6 +1773,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     };
     auto rk_store = [&](const uint4 (&rk)[2]) {
         if (COUNTS) {
+            static_assert(!COUNTS || TG == 32, "32 threads per chunk fetch the round tables");
             uint4 *dst = reinterpret_cast<uint4 *>(&s_rk0[threadIdx.x >> 5][(threadIdx.x & 31u) * 8u]);
             dst[0] = rk[0];
             dst[1] = rk[1];
@@ -1780,7 +1782,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     // 16 entries in flight per thread as four 16-byte loads (buckets start on 128-byte boundaries, their fill marks are
     // multiples of four entries: a load never straddles two buckets; k_tile_bin pads its runs)
     auto stream = [&](uint32_t buf) {
-        const uint32_t total = s_pref[buf][TEST_GROUP];
+        const uint32_t total = s_pref[buf][TG];
         uint32_t ci = 0;  // bucket of the thread's current position (positions only grow)
         for (uint32_t v0 = threadIdx.x * 4u; v0 < total; v0 += blockDim.x * 4u * TEST_LOADS) {
             uint4 en[TEST_LOADS];
@@ -1829,9 +1831,12 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
                         const uint32_t off = ev[c] & ((1u << TL) - 1u);
                         const uint32_t bad = (ev[c] >> 24) & ~(uint32_t)reinterpret_cast<const uint8_t *>(s_tile)[off];
                         if (bad) {  // candidates whose bit is 0; only what this block has not reported yet goes to memory
+                            // (a candidate over a mutation fails hundreds of probes: a plain read sorts out the repeats)
                             const uint32_t lp = (ev[c] >> TL) & ((1u << CL) - 1u), fb = cidx[u] + lp, sh = 8u * (fb & 3u);
-                            const uint32_t fresh = bad & ~(atomicOr(&s_failed[fb >> 2], bad << sh) >> sh);
-                            for (uint32_t m = fresh; m; m &= m - 1u) a.failb[((uint64_t)(first[u] + lp) << 3) + (uint32_t)__ffs((int)m) - 1u] = 1;
+                            if (bad & ~(s_failed[fb >> 2] >> sh)) {
+                                const uint32_t fresh = bad & ~(atomicOr(&s_failed[fb >> 2], bad << sh) >> sh);
+                                for (uint32_t m = fresh; m; m &= m - 1u) a.failb[((uint64_t)(first[u] + lp) << 3) + (uint32_t)__ffs((int)m) - 1u] = 1;
+                            }
                         }
                     }
                 } else {
@@ -1850,52 +1855,47 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
         }
     };
 
+    // The unit of the pipeline is (task, group of TG chunks of the task's column): while a unit's entries stream, the
+    // next unit's bucket descriptors (and round tables) are fetched into the other half of the descriptor arrays, and — when
+    // the next unit belongs to another task — its tile into registers.  (A column of a family workload has hundreds of
+    // chunks: fetching every group's descriptors where they are needed cost 9 of 16 ms.)
     uint64_t task = valid_task(blockIdx.x);
     if (task >= n_tasks) return;
-    uint32_t buf = 0;
+    uint32_t buf = 0, g0 = a.leaf_chunk0[(uint32_t)(task / a.n_tiles)];
     {
         const uint32_t leaf = (uint32_t)(task / a.n_tiles), t = (uint32_t)(task % a.n_tiles);
         uint2 v[TV];
         uint4 rk[2];
         tile_loads(leaf, t, v);
-        rk_loads(a.leaf_chunk0[leaf], rk);
-        if (threadIdx.x < 64) describe(0, leaf, t, a.leaf_chunk0[leaf]);
+        rk_loads(g0, rk);
+        if (threadIdx.x < 64) describe(0, leaf, t, g0);
         tile_store(v);
         rk_store(rk);
         __syncthreads();
     }
-    while (task < n_tasks) {
+    while (true) {
         const uint32_t leaf = (uint32_t)(task / a.n_tiles), t = (uint32_t)(task % a.n_tiles);
-        const uint64_t nxt = valid_task(task + gridDim.x);
-        const bool have_nxt = nxt < n_tasks;
-        const uint32_t nleaf = have_nxt ? (uint32_t)(nxt / a.n_tiles) : 0u, nt = have_nxt ? (uint32_t)(nxt % a.n_tiles) : 0u;
+        // the next unit: the column's next group (it may turn out empty), else the first group of the block's next task
+        const bool more = s_misc[buf][0] == TG;  // (block-uniform)
+        const uint64_t ntask = more ? task : valid_task(task + gridDim.x);
+        const bool have_n = ntask < n_tasks;
+        const uint32_t nleaf = have_n ? (uint32_t)(ntask / a.n_tiles) : 0u, nt = have_n ? (uint32_t)(ntask % a.n_tiles) : 0u;
+        const uint32_t ng0 = more ? g0 + TG : (have_n ? a.leaf_chunk0[nleaf] : 0u);
         uint2 vn[TV];
         uint4 rkn[2];
-        if (have_nxt) tile_loads(nleaf, nt, vn);  // in flight while this task's entries stream
-        if (have_nxt) rk_loads(a.leaf_chunk0[nleaf], rkn);
-        if (have_nxt && threadIdx.x < 64) describe(buf ^ 1u, nleaf, nt, a.leaf_chunk0[nleaf]);
-        for (uint32_t g0 = a.leaf_chunk0[leaf];;) {
-            stream(buf);
-            if (s_misc[buf][0] < TEST_GROUP) break;  // (block-uniform) the column has no more chunks
-            g0 += TEST_GROUP;                         // (more than 32 chunks for one column) the next 32, same tile
-            __syncthreads();
-            if (threadIdx.x < 64) describe(buf, leaf, t, g0);
-            if (COUNTS) {
-                uint4 rk[2];
-                rk_loads(g0, rk);
-                rk_store(rk);
-            } else {
-                for (uint32_t i = threadIdx.x; i < N_FAILED; i += blockDim.x) s_failed[i] = 0;
-            }
-            __syncthreads();
-        }
-        __syncthreads();  // everybody is done with this task's tile and descriptors; the next task's descriptors are written
-        if (have_nxt) {
-            tile_store(vn);
-            rk_store(rkn);
-        }
+        if (have_n && !more) tile_loads(nleaf, nt, vn);  // in flight while this unit's entries stream
+        if (have_n) rk_loads(ng0, rkn);
+        if (have_n && threadIdx.x < 64) describe(buf ^ 1u, nleaf, nt, ng0);
+        stream(buf);
+        __syncthreads();  // everybody is done with this unit's tile, descriptors and tables; the next unit's descriptors are written
+        if (!have_n) break;
+        if (!more) tile_store(vn);  // (clears the bitmap of reported failures)
+        else if (!COUNTS)
+            for (uint32_t i = threadIdx.x; i < N_FAILED; i += blockDim.x) s_failed[i] = 0;
+        rk_store(rkn);
         __syncthreads();
-        task = nxt;
+        task = ntask;
+        g0 = ng0;
         buf ^= 1u;
     }
 }
@@ -1905,7 +1905,7 @@ void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         // (static LDS of the k-mer-entry build: the 32 KiB of round_k0 rows; static + dynamic must stay within the CU's 160 KiB)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << (TILE_LOG2_COUNTS - 3));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << TILE_LOG2_BLOCK);
         attr_set = true;
     }
     const dim3 g((blocks + 1) / 2), b(1024);
