@@ -422,7 +422,9 @@ def oracle_check_and_baseline(tree, reads, n_g, ids, B, rl, args, np, torch, sub
     for row, v in enumerate(keep):
         ot.bits[row] = tree.node_filter(v)
         ot.filter_of[v] = row
-    chunk, done, secs, probes = 20000, 0, 0.0, 0
+    # (PFQ_BENCH_PARITY_READS: scenario runs whose oracle is slow — ten thousand leaves at threshold 0.3 — check fewer reads)
+    chunk, done, secs, probes = int(os.environ.get("PFQ_BENCH_PARITY_READS", "20000")), 0, 0.0, 0
+    n_parity = chunk
     t_wall = time.perf_counter()
     gpu_check = None
     while done + chunk <= B and (gpu_check is None or (time_it and (time.perf_counter() - t_wall) < args.cpu_seconds)):
@@ -440,7 +442,7 @@ def oracle_check_and_baseline(tree, reads, n_g, ids, B, rl, args, np, torch, sub
         secs += s
         probes += p
         chunk = min(chunk * 2, 200000)
-    out = {"gpu_parity_on_sample": gpu_check or "skipped", "parity_sample": "first 20000 reads of step 0, per-leaf counts"}
+    out = {"gpu_parity_on_sample": gpu_check or "skipped", "parity_sample": f"first {n_parity} reads of step 0, per-leaf counts"}
     if time_it:
         out.update({"value": done / secs if secs > 0 else 0.0, "unit": "reads/s", "cores": cores, "kind": "port",
                     "sample": f"first {done} reads of step 0 (same tree copied back from HBM); oracle in reference-faithful mode "

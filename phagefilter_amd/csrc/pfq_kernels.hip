@@ -343,7 +343,11 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
     // The screen may stop after ANY prefix of the k-mers — a leaf is dropped only for misses it has seen, what is left
     // is certified exactly — and the first maxmiss + 1 (+ a few for foreign leaves' lucky first bits) already empty the
     // frontier of a read that hits nothing; a read that does hit would otherwise walk all its k-mers for nothing.
-    const uint32_t n_scr = n < maxmiss + 1u + SCREEN_EXTRA ? n : maxmiss + 1u + SCREEN_EXTRA;
+    // (filters that are fuller than a per cent leave lucky leaves alive after that many — 2 % of the leaves survive 65 k-mers
+    // at a fill of 7 %, none 81: the limit moves on, a pass at a time, while a leaf of the read is alive but within 2^b misses
+    // of dying, 2^b about half of maxmiss; leaves that miss few k-mers — the read's real candidates — do not prolong it)
+    uint32_t n_scr = (maxmiss + 1u + SCREEN_EXTRA + lpr - 1u) & ~(lpr - 1u);  // (whole passes: the lanes are there anyway)
+    if (n_scr > n) n_scr = n;
     irregular = 0;
     {
         uint64_t b = ballot64(in_group && !regular && q == 0);
@@ -385,7 +389,7 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
         if (ballot64(active) == 0) break;
         if (pos - seg_pos >= seg_kmers || pos == 0) {  // (wave-uniform)
             seg_pos = pos;
-            const uint32_t kn = active ? (n_scr - pos < seg_kmers ? n_scr - pos : seg_kmers) : 0u;
+            const uint32_t kn = active ? (n - pos < seg_kmers ? n - pos : seg_kmers) : 0u;  // (to the read's end: the limit may move)
             W = kn ? kn + k - 1u : 0u;
             __builtin_amdgcn_wave_barrier();
             // six bytes per lane and batch; the loads are unconditional (clamped address) so that none waits for another
@@ -456,6 +460,21 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
         uint32_t any = live[0] | live[1] | live[2] | live[3];
         for (uint32_t sft = 1; sft < lpr; sft <<= 1) any |= (uint32_t)__shfl_xor((int)any, (int)sft);
         alive = alive && any != 0;
+        if (ballot64(alive && pos + lpr >= n_scr && n_scr < n)) {  // a read at its limit: leaves about to die prolong it
+            // counter = 2^P - 1 - maxmiss + misses: the planes b .. P-1 all set <=> misses > maxmiss - 2^b (complemented planes: all clear)
+            const uint32_t b = 31u - (uint32_t)__clz((int)((maxmiss >> 1) | 1u));
+            uint32_t nearw = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) {
+                uint32_t o = 0;
+#pragma unroll
+                for (uint32_t p = 0; p < P; ++p) o |= (p >= b) ? c[p][w] : 0u;
+                nearw |= live[w] & ~o;
+            }
+            uint32_t near = nearw != 0u ? 1u : 0u;
+            for (uint32_t sft = 1; sft < lpr; sft <<= 1) near |= (uint32_t)__shfl_xor((int)near, (int)sft);
+            if (alive && pos + lpr >= n_scr && near) n_scr = n_scr + lpr < n ? n_scr + lpr : n;
+        }
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll

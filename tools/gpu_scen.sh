@@ -27,6 +27,6 @@ fam8d0) run fam8d0 PFQ_BENCH_FAMILY=8 PFQ_BENCH_DIVERGENCE=0 -- ;;
 t1blk) run t1blk PFQ_BLOCK=1 -- ;;
 fam8t03) run fam8t03 PFQ_BENCH_FAMILY=8 -- --threshold 0.3 ;;
 harness) run harness X=1 -- --leaves 10010 --nbits 11981322 --hashes 17 --k 20 --read-len 100 ;;
-harness03) run harness03 X=1 -- --leaves 10010 --nbits 11981322 --hashes 17 --k 20 --read-len 100 --threshold 0.3 ;;
+harness03) run harness03 PFQ_BENCH_PARITY_READS=500 -- --leaves 10010 --nbits 11981322 --hashes 17 --k 20 --read-len 100 --threshold 0.3 ;;
 esac || exit 1
 done
