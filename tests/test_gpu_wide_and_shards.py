@@ -313,6 +313,48 @@ def test_block_mode_forced(gpu, n_genomes, k, nbits, h):
     gt.close()
 
 
+def test_prefix_certificates_and_round_overflow(gpu):
+    """Thresholds below 1 through the LDS-tile passes with k-mer entries.  (a) The passes bin only a prefix of a read's
+    k-mers (need + slack): reads whose errors sit in the prefix pass only thanks to their tail, or fail for good — both are
+    left undecided by the prefix and counted in full by the record kernel.  (b) One leaf receives thousands of pairs of
+    long reads: more rounds per chunk than the entries' tags can name, the rest of the chunk takes the fallback."""
+    k, nbits, h = 21, 262144, 5
+    genomes = [rand_dna(3000) for _ in range(12)]
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    gt = gpu_tree(genomes, ids, k, nbits, h)
+    acgt = b"ACGT"
+
+    def mutate(read, positions):
+        r = bytearray(read)
+        for p_ in positions:
+            r[p_] = acgt[(acgt.index(bytes([r[p_]])) + 1) % 4]
+        return bytes(r)
+
+    reads = []
+    for i in range(400):
+        g = genomes[i % 12]
+        o = int(RNG.integers(0, 3000 - 150))
+        rd = g[o:o + 150]
+        reads.append(rd)                                           # clean
+        reads.append(mutate(rd, [10, 30, 50, 70]))                 # prefix ruined, tail of 59 clean k-mers: passes at 0.3 only
+        reads.append(mutate(rd, [10, 30, 50, 70, 90, 110, 130]))   # ruined throughout: fails
+        reads.append(mutate(rd, [100, 120, 140]))                  # tail ruined, prefix clean: decided by the prefix
+    for thr in (0.3, 0.45, 0.7):
+        st = check_query(gt, ot, reads, thr, path=1)
+        assert st.path == 1 and st.tile_mode == 1
+    # (b) 3000 reads of 600 bp from one genome: 3000 pairs in one leaf's bucket, 580 k-mers each
+    long_reads = []
+    for i in range(3000):
+        o = int(RNG.integers(0, 3000 - 600))
+        rd = genomes[3][o:o + 600]
+        long_reads.append(mutate(rd, [int(x) for x in RNG.integers(0, 600, 3)]) if i % 3 == 0 else rd)
+    long_reads += [genomes[5][:600], genomes[6][100:700]]
+    for thr in (0.5, 0.9):
+        st = check_query(gt, ot, long_reads, thr, path=1)
+        assert st.path == 1 and st.tile_mode == 1 and st.n_fallback_pairs > 0
+    gt.close()
+
+
 def test_harness_geometry_10010_genomes_on_one_gpu(gpu):
     """The reference's own benchmark configuration names a 10 010-genome database (benchmarking/config.yaml:2) at the
     harness's filter geometry (--false-pos-rate 0.00001 --largest-genome 500000: 11 981 322 bits, 17 hashes, k = 20;
