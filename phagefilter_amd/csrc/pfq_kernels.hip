@@ -384,10 +384,9 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
     const uint32_t seg_cap = stride - 2u * WIN_PAD;
     const uint32_t seg_kmers = ((seg_cap - k + 1u) / lpr) * lpr;  // (>= lpr: stride >= 84 bytes, k <= 64, lpr <= stride / 21)
     uint32_t seg_pos = 0, W = 0;  // first k-mer of the staged segment; bytes staged for my read
-    for (uint32_t pos = 0;; pos += lpr) {
+    auto one_pass = [&](const uint32_t pos, const bool restage) {  // k-mers pos .. pos + lpr - 1 of the reads that are still active
         const bool active = alive && pos < n_scr;
-        if (ballot64(active) == 0) break;
-        if (pos - seg_pos >= seg_kmers || pos == 0) {  // (wave-uniform)
+        if (pos - seg_pos >= seg_kmers || pos == 0 || restage) {  // (wave-uniform)
             seg_pos = pos;
             const uint32_t kn = active ? (n - pos < seg_kmers ? n - pos : seg_kmers) : 0u;  // (to the read's end: the limit may move)
             W = kn ? kn + k - 1u : 0u;
@@ -422,7 +421,7 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
         // read with two 16-byte reads; k-mers that do not exist point at the all-ones row behind S (no miss)
         live_out[lane] = valid ? mod_d(h1, a.hp) : a.ones_row;
         __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
+#pragma unroll 1  // (rows of 64 words: two batches of eight gathers; unrolled, the sixteen cost the third wave per SIMD: 33.8 -> 41.4 ms)
         for (uint32_t t0 = 0; t0 < lpr; t0 += 8u) {
             const uint4 xa = *reinterpret_cast<const uint4 *>(live_out + (j << lpr_log2) + t0);
             const uint4 xb = *reinterpret_cast<const uint4 *>(live_out + (j << lpr_log2) + t0 + 4u);
@@ -460,21 +459,36 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
         uint32_t any = live[0] | live[1] | live[2] | live[3];
         for (uint32_t sft = 1; sft < lpr; sft <<= 1) any |= (uint32_t)__shfl_xor((int)any, (int)sft);
         alive = alive && any != 0;
-        if (ballot64(alive && pos + lpr >= n_scr && n_scr < n)) {  // a read at its limit: leaves about to die prolong it
-            // counter = 2^P - 1 - maxmiss + misses: the planes b .. P-1 all set <=> misses > maxmiss - 2^b (complemented planes: all clear)
-            const uint32_t b = 31u - (uint32_t)__clz((int)((maxmiss >> 1) | 1u));
-            uint32_t nearw = 0;
+    };
+    uint32_t pos = 0;
+    for (;; pos += lpr) {
+        if (ballot64(alive && pos < n_scr) == 0) break;
+        one_pass(pos, false);
+    }
+    // Reads that are still alive at their limit: while one of their live leaves is about to die, one more pass (rare where
+    // the filters are a per cent full; kept out of the loop above, where it cost 3 - 7 %).  `pos` is where the slowest read
+    // of the wave stopped — a multiple of lpr at or past every read's limit; a read that goes on takes k-mers pos .. pos +
+    // lpr - 1: skipping k-mers is as valid as stopping.  Its bytes are staged anew (a segment staged while it was idle
+    // does not hold them).
+    for (;; pos += lpr) {
+        const bool cand = alive && pos < n;
+        if (ballot64(cand) == 0) break;
+        // counter = 2^P - 1 - maxmiss + misses: the planes b .. P-1 all set <=> misses > maxmiss - 2^b (complemented planes: all clear)
+        const uint32_t b = 31u - (uint32_t)__clz((int)((maxmiss >> 1) | 1u));
+        uint32_t nearw = 0;
 #pragma unroll
-            for (uint32_t w = 0; w < 4; ++w) {
-                uint32_t o = 0;
+        for (uint32_t w = 0; w < 4; ++w) {
+            uint32_t o = 0;
 #pragma unroll
-                for (uint32_t p = 0; p < P; ++p) o |= (p >= b) ? c[p][w] : 0u;
-                nearw |= live[w] & ~o;
-            }
-            uint32_t near = nearw != 0u ? 1u : 0u;
-            for (uint32_t sft = 1; sft < lpr; sft <<= 1) near |= (uint32_t)__shfl_xor((int)near, (int)sft);
-            if (alive && pos + lpr >= n_scr && near) n_scr = n_scr + lpr < n ? n_scr + lpr : n;
+            for (uint32_t p = 0; p < P; ++p) o |= (p >= b) ? c[p][w] : 0u;
+            nearw |= live[w] & ~o;
         }
+        uint32_t near = nearw != 0u ? 1u : 0u;
+        for (uint32_t sft = 1; sft < lpr; sft <<= 1) near |= (uint32_t)__shfl_xor((int)near, (int)sft);
+        const bool go = cand && near != 0u;
+        if (ballot64(go) == 0) break;
+        n_scr = go ? (pos + lpr < n ? pos + lpr : n) : 0u;
+        one_pass(pos, true);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll

@@ -157,6 +157,28 @@ def test_wide_trees_all_thresholds(gpu, n_genomes):
     gt.close()
 
 
+@pytest.mark.parametrize("n_genomes,nbits,h", [(300, 8009, 3), (1100, 16001, 2)])
+def test_counting_screen_on_full_filters(gpu, n_genomes, nbits, h):
+    """Thresholds below 1 against filters that are 10 % (and more) full: foreign leaves survive the screen's first
+    maxmiss + 9 k-mers by luck, so reads at their limit go on while a live leaf is about to die — reads of mixed lengths in
+    one wave (the limits differ; a read that goes on after a longer neighbour's segment was staged gets its bytes anew)."""
+    k = 21
+    genomes = [rand_dna(int(RNG.integers(250, 400))) for _ in range(n_genomes)]
+    genomes[5] = genomes[4]
+    ot, ids = oracle_tree(genomes, k, nbits, h)
+    gt = gpu_tree(genomes, ids, k, nbits, h)
+    reads = []
+    for L in (60, 100, 150, 151, 220, 250):
+        reads += make_reads(genomes, 120, 60, L, k)
+    RNG.shuffle(reads)
+    reads += make_reads(genomes, 10, 5, 600, k)            # a few long ones (>= 256 k-mers: the wide-counter launch)
+    for thr in (0.3, 0.5, 0.8):
+        for path in (0, 1):
+            st = check_query(gt, ot, reads, thr, path=path)
+            assert st.path == path
+    gt.close()
+
+
 @pytest.mark.parametrize("n_genomes,k,nbits,h", TREES)
 def test_query_matches_oracle(gpu, n_genomes, k, nbits, h):
     genomes = [rand_dna(int(RNG.integers(300, 1500))) for _ in range(n_genomes)]

@@ -26,6 +26,10 @@ fam8) run fam8 PFQ_BENCH_FAMILY=8 -- ;;
 fam8d0) run fam8d0 PFQ_BENCH_FAMILY=8 PFQ_BENCH_DIVERGENCE=0 -- ;;
 t1blk) run t1blk PFQ_BLOCK=1 -- ;;
 fam8t03) run fam8t03 PFQ_BENCH_FAMILY=8 -- --threshold 0.3 ;;
+l64) run l64 X=1 -- --leaves 64 ;;
+l2048) run l2048 X=1 -- --leaves 2048 ;;
+l4096) run l4096 X=1 -- --leaves 4096 ;;
+long1k) run long1k X=1 -- --read-len 1000 --reads-per-step 1048576 --threshold 0.5 ;;
 harness) run harness X=1 -- --leaves 10010 --nbits 11981322 --hashes 17 --k 20 --read-len 100 ;;
 harness03) run harness03 PFQ_BENCH_PARITY_READS=500 -- --leaves 10010 --nbits 11981322 --hashes 17 --k 20 --read-len 100 --threshold 0.3 ;;
 esac || exit 1
