@@ -14,6 +14,8 @@
 // Reference semantics: query.rs:38-158, bloom_filter.rs:312-332, hash_iter.rs:13-45, file_parser.rs:114-148.
 #include "pfq_kernels.h"
 
+#include <atomic>
+
 namespace pfq {
 
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((31u << 11) | 20u) & 0xFu; }
@@ -1679,14 +1681,20 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
         for (uint32_t t = threadIdx.x; t < a.n_tiles; t += blockDim.x) a.gfill[(uint64_t)c * a.n_tiles + t] = fillp[t];
     }
 }
+// Function attributes are set once per device (the CLI runs replicas on several GPUs from one process).
+static bool first_on_device(std::atomic<uint64_t> &done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    return !(done.fetch_or(bit) & bit);
+}
 template <uint32_t W, uint32_t CAP>
 static void launch_tile_bin_shape(const TileArgs &a, int blocks, size_t lds, hipStream_t st) {
-    static bool attr_set = false;  // (per instantiation)
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};  // (per instantiation; a bit per device: replicas on several GPUs in one process)
+    if (first_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
     }
     if (a.counts) hipLaunchKernelGGL((k_tile_bin<W, CAP, 1>), dim3(blocks), dim3(W * 64), lds, st, a);
     else if (a.blocks) hipLaunchKernelGGL((k_tile_bin<W, CAP, 2>), dim3(blocks), dim3(W * 64), lds, st, a);
@@ -1933,13 +1941,12 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     }
 }
 void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (first_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         // (static LDS of the k-mer-entry build: the 32 KiB of round_k0 rows; static + dynamic must stay within the CU's 160 KiB)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << (TILE_LOG2_COUNTS - 3));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << TILE_LOG2_BLOCK);
-        attr_set = true;
     }
     const dim3 g((blocks + 1) / 2), b(1024);
     if (a.counts) hipLaunchKernelGGL(k_tile_test<1>, g, b, (size_t)(1u << (TILE_LOG2_COUNTS - 3)), st, a);

@@ -761,8 +761,10 @@ def test_randomized_parity(gpu, seed):
     entries = int(rng.choice([0, 0, 30_000, 400_000, 5_000_000]))
     if entries:
         os.environ["PFQ_TILE_ENTRIES"] = str(entries)
-    if seed % 2:
-        os.environ["PFQ_TILE_COUNTS"] = "1"   # thresholds < 1 through the LDS-tile passes whatever the share of clean pairs
+    if seed % 3 == 1:
+        os.environ["PFQ_TILE_COUNTS"] = "0"   # thresholds < 1: the record kernel counts alone (default: LDS-tile passes with k-mer entries)
+    if seed % 3 == 2:
+        os.environ["PFQ_BLOCK"] = "1"         # threshold 1: block mode from the first call (default: once reads pass several leaves)
     try:
         gt = gpu_tree(genomes, ids, k, nbits, h)
         for thr in (1.0, float(rng.choice([0.05, 0.3, 0.5, 0.9])), float(rng.choice([0.0, 0.2, 0.75, 0.999, 1.5]))):
@@ -772,3 +774,4 @@ def test_randomized_parity(gpu, seed):
     finally:
         os.environ.pop("PFQ_TILE_ENTRIES", None)
         os.environ.pop("PFQ_TILE_COUNTS", None)
+        os.environ.pop("PFQ_BLOCK", None)
