@@ -640,8 +640,12 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     // than 1.5 candidate leaves per read (PFQ_BLOCK=1 / 0 forces / forbids it).  Results do not depend on the choice.
     const uint64_t n_blocks = (nl + 7) / 8;
     const uint32_t n_tiles_block = (uint32_t)((t.n_words * 64 + (1ull << pfq::TILE_LOG2_BLOCK) - 1) >> pfq::TILE_LOG2_BLOCK);
-    bool block_mode = bucketed && thr_one && !with_guards && recs_possible && n_tiles_block <= 560 && n_blocks < (1u << 24) &&
-                      (kn.block >= 0 ? kn.block != 0 : t.cand_per_read > 1.5) && (kn.tile < 0 || kn.tile != 0);
+    // (Guard columns — reference-built trees whose internal names collide: the guards of a hit are certified against the
+    // sliced matrix afterwards, 1300 line gathers each, which pays while few leaves have guards: <= 5 % of them.)
+    size_t guarded = 0;
+    for (size_t c = 0; with_guards && c < nl; ++c) guarded += t.guard_off[c + 1] > t.guard_off[c];
+    bool block_mode = bucketed && thr_one && recs_possible && n_tiles_block <= 560 && n_blocks < (1u << 24) &&
+                      (kn.block >= 0 ? kn.block != 0 : (t.cand_per_read > 1.5 && guarded * 20 <= nl)) && (kn.tile < 0 || kn.tile != 0);
     if (block_mode && !soft_ensure(t.d_T, n_blocks * t.n_words * 64)) block_mode = false;
     if (block_mode && !soft_ensure(t.d_failb, t.d_pairs.n * 8)) block_mode = false;
     if (block_mode) nc = n_blocks;
@@ -760,7 +764,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 }
                 PFQ_TRY(classify_groups(true));
                 pfq::GuardArgs ga{};
-                if (with_guards) {  // every guard of a deferred pair's leaf becomes a pair of its own (second region of the buffer)
+                if (with_guards && !block_mode) {  // every guard of a deferred pair's leaf becomes a pair of its own (second region of the buffer)
                     ga.pairs = t.d_pairs.p + t.leaf_cap;
                     ga.cap = t.guard_cap;
                     ga.cursor = t.d_cursors.p + 8;
@@ -776,8 +780,9 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, sub_log2, t.d_sorted.p,
                                            recs ? t.d_meta.p : nullptr, d_off, block_mode ? nullptr : t.d_col_row.p, offw, curw,
                                            counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
-                                           with_guards ? t.d_owner.p : nullptr, with_guards ? t.d_owner_sorted.p : nullptr, 1024, st);
-                if (with_guards)
+                                           (with_guards && !block_mode) ? t.d_owner.p : nullptr,
+                                           (with_guards && !block_mode) ? t.d_owner_sorted.p : nullptr, 1024, st);
+                if (with_guards && !block_mode)
                     pfq::launch_bucket_scatter(ga.pairs, ga.cursor, ga.cap, off, cur, sub_log2, t.d_sorted.p,
                                                recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, offw, curw,
                                                counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
@@ -952,6 +957,9 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                     a.n_leaves = (uint32_t)std::min<size_t>(2048, nl);
                     pfq::launch_block_fallback(a, t.d_sorted.p, off + nb, t.d_fail.p, t.d_failb.p, t.d_pair_chunk.p,
                                                t.last_tile_mode ? t.d_chunks.p : nullptr, v.launched_passes, st);
+                    // ancestors that are not provably supersets must pass too (query.rs:119-141): the guards of every candidate
+                    // that is still standing
+                    if (with_guards) pfq::launch_block_guards(a, t.d_sorted.p, off + nb, t.d_failb.p, st);
                     if (ev) HIP_TRY(hipEventRecord(ev[5], st));
                     pfq::FinalizeArgs f{};
                     f.hp = t.hp;

@@ -231,6 +231,9 @@ void launch_block_tables(const uint64_t *bits, uint64_t n_words, const uint32_t 
 // (chunks == nullptr: no tile passes ran, every pair is certified here)
 void launch_block_fallback(const QueryArgs &a, const uint2 *sorted, const uint32_t *n_pairs_ptr, const uint32_t *fail, uint8_t *failb,
                            const uint32_t *pair_chunk, const ChunkDesc *chunks, uint32_t launched_passes, hipStream_t st);
+// block mode on trees with guard columns: a candidate leaf that has not failed passes only if its guards pass (certified
+// against the sliced matrix)
+void launch_block_guards(const QueryArgs &a, const uint2 *sorted, const uint32_t *n_pairs_ptr, uint8_t *failb, hipStream_t st);
 void launch_verify(const VerifyArgs &a, int blocks, int threads, hipStream_t st);
 // list = the sorted pairs with a non-zero fail word, in order within runs; *n_out += their number (thresholds < 1 after tile passes)
 void launch_collect_open(const uint32_t *fail, const uint32_t *n_pairs_ptr, uint32_t *list, uint32_t cap, unsigned int *n_out, hipStream_t st);

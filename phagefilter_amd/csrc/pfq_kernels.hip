@@ -2072,6 +2072,50 @@ void launch_block_fallback(const QueryArgs &a, const uint2 *sorted, const uint32
     hipLaunchKernelGGL(k_block_fallback, dim3(1024), dim3(256), 0, st, a, sorted, n_pairs_ptr, fail, failb, pair_chunk, chunks, launched_passes);
 }
 
+__global__ void __launch_bounds__(256) k_block_guards(QueryArgs a, const uint2 *sorted, const uint32_t *n_pairs_ptr, uint8_t *failb) {
+    __shared__ BlockLds lds;
+    fill_complement(lds.comp);
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, n_pairs = *n_pairs_ptr;
+    const uint64_t gw = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave, nw = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (uint64_t e0 = gw * 64u; e0 < n_pairs; e0 += nw * 64u) {
+        const uint64_t e = e0 + lane;
+        uint2 p = make_uint2(0, 0);
+        uint32_t todo_mask = 0;  // candidates of my pair that are still standing and have guards
+        if (e < n_pairs) {
+            p = sorted[e];
+            const uint2 fb = *reinterpret_cast<const uint2 *>(failb + (e << 3));
+            const uint32_t c0 = (p.y & 0xffffffu) << BLOCK_LEAVES_LOG2;
+            for (uint32_t j = 0; j < 8; ++j) {
+                const uint32_t f = ((j < 4 ? fb.x : fb.y) >> (8u * (j & 3u))) & 0xffu;
+                if (((p.y >> (24 + j)) & 1u) && !f && a.guard_off[c0 + j + 1] > a.guard_off[c0 + j]) todo_mask |= 1u << j;
+            }
+        }
+        uint64_t todo = ballot64(todo_mask != 0);
+        while (todo) {
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t r = bcast_u32(p.x, src), y = bcast_u32(p.y, src), tm = bcast_u32(todo_mask, src);
+            const uint64_t o0 = a.off[r], L = a.off[r + 1] - o0;
+            ReadCtx rc;
+            rc.read = a.seq + o0;
+            rc.n = L - a.hp.k + 1;
+            rc.need = need_kmers(a.threshold, rc.n);
+            rc.maxmiss = rc.n - rc.need;
+            for (uint32_t j = 0; j < 8; ++j) {
+                if (!((tm >> j) & 1u)) continue;
+                const uint32_t col = ((y & 0xffffffu) << BLOCK_LEAVES_LOG2) + j;
+                bool pass = true;
+                for (uint32_t g = a.guard_off[col]; pass && g < a.guard_off[col + 1]; ++g) pass = verify_column(lds, wave, a, rc, a.guard_col[g]);
+                if (!pass && lane == 0) failb[((e0 + (uint32_t)src) << 3) + j] = 1;
+            }
+        }
+    }
+}
+void launch_block_guards(const QueryArgs &a, const uint2 *sorted, const uint32_t *n_pairs_ptr, uint8_t *failb, hipStream_t st) {
+    hipLaunchKernelGGL(k_block_guards, dim3(1024), dim3(256), 0, st, a, sorted, n_pairs_ptr, failb);
+}
+
 // One block per leaf bucket: pairs that no slice failed are hits (mapped_reads += |pass|, query.rs:143).
 __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
     __shared__ unsigned long long s_cnt, s_bytes;

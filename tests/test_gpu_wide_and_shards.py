@@ -83,6 +83,17 @@ def test_colliding_internal_names_stay_on_the_bucketed_path(gpu, tmp_path):
                 assert check_query(gt, ot, reads, 0.6, path=1).path == 1
         finally:
             gt.set_option(key, None)
+    # block mode on a tree with guard columns: the guards of the candidates that stand are certified against the sliced matrix
+    gt.set_option("PFQ_BLOCK", "1")
+    for env in ({}, {"PFQ_TILE_ENTRIES": "20000"}):
+        for key, val in env.items():
+            gt.set_option(key, val)
+        try:
+            st = check_query(gt, ot, reads, 1.0, path=1)
+            assert st.path == 1 and st.tile_mode == 2
+        finally:
+            for key in env:
+                gt.set_option(key, None)
     gt.close()
 
 
@@ -97,6 +108,8 @@ def test_guards_and_column_groups_together(gpu, tmp_path):
     for thr in (1.0, 0.7):
         assert check_query(gt, ot, reads, thr, path=1).path == 1
         check_query(gt, ot, reads, thr, path=0)
+    gt.set_option("PFQ_BLOCK", "1")
+    assert check_query(gt, ot, reads, 1.0, path=1).tile_mode == 2
     gt.close()
 
 
@@ -453,6 +466,8 @@ def test_randomized_parity_with_colliding_names(gpu, tmp_path, seed):
         os.environ["PFQ_TILE_ENTRIES"] = str(entries)
     if seed % 2:
         os.environ["PFQ_TILE_COUNTS"] = "0"   # (record kernel alone; default: tile passes with k-mer entries)
+    if seed % 3 == 0:
+        os.environ["PFQ_BLOCK"] = "1"         # (block mode with guard columns)
     try:
         gt = BloomTree.load(d)
         for thr in (1.0, float(rng.choice([0.1, 0.5, 0.9])), float(rng.choice([0.0, 0.75, 0.999]))):
@@ -462,3 +477,4 @@ def test_randomized_parity_with_colliding_names(gpu, tmp_path, seed):
     finally:
         os.environ.pop("PFQ_TILE_ENTRIES", None)
         os.environ.pop("PFQ_TILE_COUNTS", None)
+        os.environ.pop("PFQ_BLOCK", None)
