@@ -516,11 +516,12 @@ __device__ __forceinline__ bool has_batched_tail(uint64_t n) {
 // ---- the classification kernel ---------------------------------------------------------------------------------------
 // LPR_LOG2 (thresholds < 1): log2 of the lanes per read of the dense counting screen, rw = 4 << LPR_LOG2 (16, 32 or 64 row
 // words: a build per row width keeps the screen free of run-time shapes); 0: rows narrower than 16 words, per-read screen.
-// (the counting build is held to three waves per SIMD — 168 VGPRs; the allocator stops a few registers above on its own)
+// (the counting builds for rows of 16 and 32 words are held to three waves per SIMD — 168 VGPRs; the allocator stops a few
+// registers above on its own.  The 64-word build is left alone: bounded, it spills and the harness geometry loses 6 %.)
 // BLOCKS (DEFER, theta == 1, no guard columns): survivors are deferred per block of 8 leaf columns — (read, block | mask of
 // the candidate leaves << 24) — see TILE_LOG2_BLOCK.
 template <bool DEFER, bool COUNTS, bool LONG = false, uint32_t LPR_LOG2 = 0, bool BLOCKS = false>
-__global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0) ? 3 : 1) k_classify(QueryArgs a) {
+__global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_LOG2 != 4) ? 3 : 1) k_classify(QueryArgs a) {
     __shared__ BlockLds lds;
     __shared__ DenseLds<(DEFER && !LONG) || COUNTS> dlds;
     fill_complement(lds.comp);
