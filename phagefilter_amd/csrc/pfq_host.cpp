@@ -164,6 +164,7 @@ struct pfq_tree {
     DevBuf<pfq::ChunkDesc> d_chunks;
     DevBuf<unsigned int> d_gfill, d_binq;
     DevBuf<uint8_t> d_kmiss;
+    DevBuf<uint8_t> d_kall;            // block mode with k-mer entries: per k-mer, "in no candidate leaf of the block"
     DevBuf<uint8_t> d_T, d_failb;      // block mode: byte-per-index tables of the blocks of 8 leaves; failure bytes per (pair, leaf)
     bool tables_valid = false;         // d_T matches the current leaf set
     double cand_per_read = 1.0;        // candidate leaves per read seen by recent calls (related genomes: several): chooses block mode
@@ -644,11 +645,12 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     // sliced matrix afterwards, 1300 line gathers each, which pays while few leaves have guards: <= 5 % of them.)
     size_t guarded = 0;
     for (size_t c = 0; with_guards && c < nl; ++c) guarded += t.guard_off[c + 1] > t.guard_off[c];
-    bool block_mode = bucketed && thr_one && recs_possible && n_tiles_block <= 560 && n_blocks < (1u << 24) &&
+    // At thresholds below 1 block mode keeps the k-mer entries: buckets by (block, candidate mask), 8 miss bytes per k-mer.
+    bool block_mode = bucketed && (thr_one || (thr_frac && kn.tile_counts != 0)) && recs_possible && n_tiles_block <= 560 && n_blocks < (1u << 16) * (thr_one ? 256u : 1u) &&
                       (kn.block >= 0 ? kn.block != 0 : (t.cand_per_read > 1.5 && guarded * 20 <= nl)) && (kn.tile < 0 || kn.tile != 0);
     if (block_mode && !soft_ensure(t.d_T, n_blocks * t.n_words * 64)) block_mode = false;
     if (block_mode && !soft_ensure(t.d_failb, t.d_pairs.n * 8)) block_mode = false;
-    if (block_mode) nc = n_blocks;
+    if (block_mode) nc = counts_mode ? n_blocks * 256 : n_blocks;
     t.last_block_mode = 0;
     uint64_t miss_cap = 0;
     size_t nb = 0;
@@ -657,7 +659,8 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
         // sub-buckets (keyed by the read index) keep every histogram counter cold when columns are few
         while (sub_log2 < 6 && (nc << sub_log2) < 1024) ++sub_log2;
         nb = nc << sub_log2;
-        if (counts_mode) {  // thresholds < 1: every deferred pair owns ceil(n/64) words of k-mer miss bits that the slices OR into
+        if (block_mode && !soft_ensure(t.d_bucket, 3 * nb + 2)) bucketed = false;  // (buckets by (block, mask) outnumber the columns of small trees)
+        if (counts_mode && !block_mode) {  // thresholds < 1: every deferred pair owns ceil(n/64) words of k-mer miss bits that the slices OR into
             const uint64_t avg_len = n_reads ? total_bytes / n_reads : 0;
             miss_cap = std::min<uint64_t>((t.leaf_cap + t.guard_cap) * ((avg_len >> 6) + 2) + 4 * CLASSIFY_MAX_BLOCKS * 1024ull, 0xfffffff0ull);
             if (!(soft_ensure(t.d_miss_words, miss_cap) && soft_ensure(t.d_miss_pos, t.d_pairs.n) && soft_ensure(t.d_bucket_w, 3 * nb + 2)))
@@ -734,7 +737,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 a.recs = recs;
                 a.rec_cap = recs ? t.d_recs.n : 0;
                 uint32_t *cntw = nullptr, *offw = nullptr, *curw = nullptr;
-                if (counts_mode) {
+                if (counts_mode && !block_mode) {
                     cntw = t.d_bucket_w.p;
                     offw = cntw + nb;
                     curw = offw + nb + 1;
@@ -776,17 +779,18 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 if (a.batch_tails) pfq::launch_tail_records(a, 2048, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
                 pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nb, st);
-                if (counts_mode) pfq::launch_bucket_scan(cntw, offw, curw, (uint32_t)nb, st);
+                if (counts_mode && !block_mode) pfq::launch_bucket_scan(cntw, offw, curw, (uint32_t)nb, st);
                 pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, sub_log2, t.d_sorted.p,
                                            recs ? t.d_meta.p : nullptr, d_off, block_mode ? nullptr : t.d_col_row.p, offw, curw,
-                                           counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
+                                           (counts_mode && !block_mode) ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
                                            (with_guards && !block_mode) ? t.d_owner.p : nullptr,
-                                           (with_guards && !block_mode) ? t.d_owner_sorted.p : nullptr, 1024, st);
+                                           (with_guards && !block_mode) ? t.d_owner_sorted.p : nullptr,
+                                           block_mode ? (counts_mode ? 2u : 1u) : 0u, 1024, st);
                 if (with_guards && !block_mode)
                     pfq::launch_bucket_scatter(ga.pairs, ga.cursor, ga.cap, off, cur, sub_log2, t.d_sorted.p,
                                                recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, offw, curw,
                                                counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
-                                               t.d_owner.p + t.leaf_cap, t.d_owner_sorted.p, 256, st);
+                                               t.d_owner.p + t.leaf_cap, t.d_owner_sorted.p, 0u, 256, st);
                 if (ev) HIP_TRY(hipEventRecord(ev[2], st));
                 pfq::VerifyArgs v{};
                 v.hp = t.hp;
@@ -799,8 +803,8 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 v.n_pairs_ptr = off + nb;
                 v.fail = t.d_fail.p;
                 v.recs = recs;
-                v.miss_words = counts_mode ? t.d_miss_words.p : nullptr;
-                v.miss_pos = counts_mode ? t.d_miss_pos.p : nullptr;
+                v.miss_words = (counts_mode && !block_mode) ? t.d_miss_words.p : nullptr;
+                v.miss_pos = (counts_mode && !block_mode) ? t.d_miss_pos.p : nullptr;
                 v.meta = t.d_meta.p;
                 v.n_slices = n_slices;
                 uint64_t sb = (t.n_words * 64 + n_slices - 1) / n_slices;
@@ -819,9 +823,9 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 // LDS-tile certificates: every probe binned by (leaf chunk, 128 KiB filter tile), tiles tested out of LDS;
                 // k_verify_rec then only sees the pairs that could not be binned
                 // (thresholds < 1: entries name k-mers, tiles are half the size — pfq::TILE_LOG2_COUNTS)
-                const uint32_t tile_log2 = counts_mode ? pfq::TILE_LOG2_COUNTS : (block_mode ? pfq::TILE_LOG2_BLOCK : pfq::TILE_LOG2);
+                const uint32_t tile_log2 = block_mode ? pfq::TILE_LOG2_BLOCK : (counts_mode ? pfq::TILE_LOG2_COUNTS : pfq::TILE_LOG2);
                 const uint32_t n_tiles = (uint32_t)((t.n_words * 64 + (1ull << tile_log2) - 1) >> tile_log2);
-                const uint32_t chunk_log2 = block_mode ? pfq::CHUNK_PAIRS_LOG2_BLOCK : pfq::CHUNK_PAIRS_LOG2;
+                const uint32_t chunk_log2 = (block_mode && !counts_mode) ? pfq::CHUNK_PAIRS_LOG2_BLOCK : pfq::CHUNK_PAIRS_LOG2;
                 // Thresholds < 1: the tile passes leave the k-mers that are not contained in per-chunk miss bitmaps; k_verify_rec
                 // only sees what could not be binned.  (PFQ_TILE_COUNTS=0: record kernel only.)  Results do not depend on the choice.
                 bool tile_counts = true;
@@ -841,12 +845,15 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                     if (kn.tile_entries >= 0) want = std::max<uint64_t>(1, (uint64_t)kn.tile_entries);  // tests: force passes
                     // thresholds < 1: one miss byte per k-mer of every pair the recent calls make expect (chunks that find no room
                     // take the fallback), the rounds' positions, the pairs' positions
-                    const uint64_t kmiss_cap = counts_mode ? std::min<uint64_t>((uint64_t)((double)total_bytes * std::max(1.0, 1.3 * t.pairs_per_read)) + 16 * max_chunks + 64, 0xfffffff0ull) & ~15ull : 0;
+                    // (block mode: 8 bytes per k-mer, one per leaf of the block; chunk offsets are in 16-byte units)
+                    const uint64_t kmiss_cap = counts_mode ? std::min<uint64_t>(((uint64_t)((double)total_bytes * std::max(1.0, 1.3 * t.pairs_per_read)) + 16 * max_chunks + 64) * (block_mode ? 8u : 1u),
+                                                                                    block_mode ? (48ull << 30) : 0xfffffff0ull) & ~15ull : 0;
                     bool ok = soft_ensure(t.d_entries, want) && soft_ensure(t.d_pair_chunk, t.d_pairs.n) && soft_ensure(t.d_flag_list, t.d_pairs.n) &&
                               soft_ensure(t.d_leaf_chunk0, nc + 1) && soft_ensure(t.d_chunks, max_chunks) && soft_ensure(t.d_gfill, max_chunks * n_tiles) && soft_ensure(t.d_binq, 256);
                     if (ok && counts_mode)
                         ok = soft_ensure(t.d_kmiss, kmiss_cap) && soft_ensure(t.d_round_k0, max_chunks * pfq::MAX_ROUNDS) &&
                              soft_ensure(t.d_n_rounds, max_chunks) && soft_ensure(t.d_pair_kpos, t.d_pairs.n);
+                    if (ok && counts_mode && block_mode) ok = soft_ensure(t.d_kall, (kmiss_cap >> 3) + 64);
                     if (!ok) {
                         tile_mode = false;  // not enough HBM for the probe buckets: stay with the record kernel
                     } else {
@@ -859,6 +866,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         ta.chunk_log2 = chunk_log2;
                         if (block_mode) {  // the "filter" of a bucket is its block's table: n_words * 64 bytes
                             ta.blocks = 1;
+                            if (counts_mode) ta.kall = t.d_kall.p;  // (buckets by (block, mask); the passes' columns are the blocks)
                             ta.bits = reinterpret_cast<const uint64_t *>(t.d_T.p);
                             ta.n_words = t.n_words * 8;
                             ta.failb = t.d_failb.p;
@@ -868,7 +876,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         ta.col_row = t.d_col_row.p;
                         ta.bucket_off = off;
                         ta.sub_log2 = sub_log2;
-                        ta.n_leaves = (uint32_t)nc;
+                        ta.n_leaves = (uint32_t)((block_mode && counts_mode) ? n_blocks : nc);  // (columns of the passes: blocks, whatever the buckets)
                         ta.n_tiles = n_tiles;
                         ta.chunks = t.d_chunks.p;
                         ta.max_chunks = (uint32_t)max_chunks;
@@ -924,7 +932,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         v.entry_cursor = t.d_cursors.p + 2;
                         v.entry_cap = ta.entry_cap;
                         v.launched_passes = (uint32_t)n_passes;
-                        if (counts_mode) {  // binned pairs whose prefix of k-mers leaves them undecided go to the record kernel
+                        if (counts_mode && !block_mode) {  // binned pairs whose prefix of k-mers leaves them undecided go to the record kernel
                             pfq::FinalizeArgs pf{};
                             pf.hp = t.hp;
                             pf.threshold = threshold;
@@ -955,6 +963,21 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                     a.S = t.d_S.p;
                     a.col0 = 0;
                     a.n_leaves = (uint32_t)std::min<size_t>(2048, nl);
+                    if (counts_mode && t.last_tile_mode) {  // the miss bytes of the binned pairs decide their candidates
+                        pfq::FinalizeArgs cf{};
+                        cf.hp = t.hp;
+                        cf.off = d_off;
+                        cf.sorted = t.d_sorted.p;
+                        cf.threshold = threshold;
+                        cf.fail = t.d_fail.p;
+                        cf.kmiss = t.d_kmiss.p;
+                        cf.kall = t.d_kall.p;
+                        cf.pair_kpos = t.d_pair_kpos.p;
+                        cf.pair_chunk = t.d_pair_chunk.p;
+                        cf.chunks = t.d_chunks.p;
+                        cf.launched_passes = v.launched_passes;
+                        pfq::launch_block_count(cf, off + nb, t.d_failb.p, st);
+                    }
                     pfq::launch_block_fallback(a, t.d_sorted.p, off + nb, t.d_fail.p, t.d_failb.p, t.d_pair_chunk.p,
                                                t.last_tile_mode ? t.d_chunks.p : nullptr, v.launched_passes, st);
                     // ancestors that are not provably supersets must pass too (query.rs:119-141): the guards of every candidate

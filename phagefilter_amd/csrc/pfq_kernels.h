@@ -129,6 +129,7 @@ struct FinalizeArgs {
     // thresholds < 1 after LDS-tile passes with k-mer entries: a pair that was binned in a launched pass and never flagged
     // has its miss bits in its chunk's bitmap (kmiss); every other pair in its own miss words (written by k_verify_rec)
     const uint8_t *kmiss;         // nullptr: miss words only
+    const uint8_t *kall;          // block mode with k-mer entries (see TileArgs)
     const uint32_t *pair_kpos;
     const uint32_t *pair_chunk;
     const ChunkDesc *chunks;
@@ -155,6 +156,9 @@ constexpr uint32_t MAX_ROUNDS = 256;               // rounds per chunk the tags 
 // is a byte per Bloom bit index — bit j = that bit of leaf 8b + j — so ONE entry tests a probe for all candidate leaves of
 // the block: a read that passes 8 strains costs the probes of one pair instead of eight.  Entry = [mask:8][pair of the
 // chunk:7][byte offset in a 128 KiB tile:17]; chunks of <= 128 pairs.
+// At thresholds below 1 block mode keeps the k-mer entries [round tag:2][k-mer:11][byte offset:17] — no room for a mask, so
+// the buckets are keyed by (block, candidate mask): all pairs of a chunk share their mask, which travels in the chunk's
+// descriptor.  The miss array holds 8 bytes per k-mer, one per leaf of the block.
 constexpr uint32_t TILE_LOG2_BLOCK = 17;           // 2^17 bit indices x 8 leaves = 128 KiB
 constexpr uint32_t CHUNK_PAIRS_LOG2_BLOCK = 7;
 constexpr uint32_t BLOCK_LEAVES_LOG2 = 3;
@@ -166,8 +170,11 @@ struct ChunkDesc {
     uint64_t base;     // first entry of tile 0's bucket
     uint32_t leaf;
     uint32_t pass;     // the probe buckets are reused: chunks are binned and tested pass after pass
-    uint32_t kbase;    // thresholds < 1: first byte of the chunk's k-mer miss array (byte = position of the k-mer in the chunk)
+    uint32_t kbase;    // thresholds < 1: where the chunk's k-mer miss array starts, in 16-byte units (a byte per k-mer of the chunk
+                       // in the order of its pairs; block mode: 8 bytes per k-mer, one per leaf of the block)
     uint32_t kwords;   //                 its size in 16-byte units
+    uint32_t mask;     // block mode with k-mer entries: the candidate mask all pairs of the chunk share
+    uint32_t pad_;
 };
 struct TileArgs {
     uint32_t pass;               // k_tile_bin / k_tile_test: only the chunks of this pass
@@ -198,6 +205,7 @@ struct TileArgs {
     const uint32_t *n_pairs_ptr;
     // block mode (see TILE_LOG2_BLOCK)
     uint32_t blocks;             // 1: pairs are (read, block | mask << 24), meta.w likewise; bits = block tables, n_words = bytes / 8 of one
+                                 // (with `counts`: buckets = (block << 8) | mask, n_leaves = blocks: a column of the passes is a block)
     uint32_t chunk_log2;         // pairs per chunk (CHUNK_PAIRS_LOG2, or CHUNK_PAIRS_LOG2_BLOCK)
     uint8_t *failb;              // block mode: [sorted pair][8] a probed bit of that candidate leaf was 0
     // thresholds < 1 (entries name k-mers, see TILE_LOG2_COUNTS)
@@ -206,6 +214,7 @@ struct TileArgs {
     uint8_t *kmiss;              // k-mer miss bytes of all chunks (a byte, not a bit: set with plain stores from any XCD)
     uint64_t kmiss_cap;          // its bytes, < 2^32 (chunks that find no room take the fallback)
     unsigned long long *kmiss_used;  // bytes handed out by k_tile_assign (cleared before the passes)
+    uint8_t *kall;               // block mode: [k-mer] the k-mer is in no candidate leaf of its pair's block (one byte for all eight)
     uint32_t *round_k0;          // [max_chunks][MAX_ROUNDS] position (in the chunk) of the first k-mer of every round
     uint32_t *n_rounds;          // [max_chunks]
     uint32_t *pair_kpos;         // [sorted pair] position of the pair's first k-mer in its chunk
@@ -219,18 +228,22 @@ void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int block
 void launch_tail_records(const QueryArgs &a, int blocks, hipStream_t st);  // after launch_classify when a.batch_tails
 void launch_bucket_scan(const uint32_t *bucket_cnt, uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t n, hipStream_t st);
 // words_off / words_cur / miss_pos: thresholds < 1 (miss words of a bucket start at words_off[bucket]); else nullptr
-// col_row == nullptr: block mode (the key of a pair is the low 24 bits of its second word, which goes to meta.w whole)
+// key_mode 0: the bucket of a pair is its column; 1 (block mode): the block = low 24 bits of its second word, which goes to
+// meta.w whole; 2 (block mode with k-mer entries): (block << 8) | candidate mask
 void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
                            const uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t sub_log2, uint2 *sorted, uint4 *meta,
                            const uint64_t *read_off, const uint32_t *col_row, const uint32_t *words_off, uint32_t *words_cur,
-                           uint32_t *miss_pos, uint32_t kmer_size, const uint32_t *owner, uint32_t *owner_sorted, int blocks,
-                           hipStream_t st);
+                           uint32_t *miss_pos, uint32_t kmer_size, const uint32_t *owner, uint32_t *owner_sorted, uint32_t key_mode,
+                           int blocks, hipStream_t st);
 // block tables: T[b][i] = byte whose bit j is bit i of the filter of leaf column 8b + j (zero for columns past the last leaf)
 void launch_block_tables(const uint64_t *bits, uint64_t n_words, const uint32_t *d_col_row, uint32_t n_leaves, uint8_t *T, hipStream_t st);
 // block mode: flagged pairs (fail bit 1) certified leaf by leaf against the sliced matrix; then the counts / hits of all pairs
 // (chunks == nullptr: no tile passes ran, every pair is certified here)
 void launch_block_fallback(const QueryArgs &a, const uint2 *sorted, const uint32_t *n_pairs_ptr, const uint32_t *fail, uint8_t *failb,
                            const uint32_t *pair_chunk, const ChunkDesc *chunks, uint32_t launched_passes, hipStream_t st);
+// block mode with k-mer entries: turns the miss bytes of the binned pairs into failure bytes (FinalizeArgs: fail, kmiss, kall,
+// pair_kpos, pair_chunk, chunks, launched_passes, sorted, off, hp, threshold)
+void launch_block_count(const FinalizeArgs &a, const uint32_t *n_pairs_ptr, uint8_t *failb, hipStream_t st);
 // block mode on trees with guard columns: a candidate leaf that has not failed passes only if its guards pass (certified
 // against the sliced matrix)
 void launch_block_guards(const QueryArgs &a, const uint2 *sorted, const uint32_t *n_pairs_ptr, uint8_t *failb, hipStream_t st);

@@ -609,9 +609,11 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
                 }
                 if (pair_used < PAIR_CHUNK) {
                     if (lane == 0) {
-                        const uint32_t key = BLOCKS ? col >> BLOCK_LEAVES_LOG2 : col;
+                        // (block mode at thresholds < 1: buckets by (block, mask) — the pairs of a chunk share their mask)
+                        const uint32_t blk = col >> BLOCK_LEAVES_LOG2;
+                        const uint32_t key = BLOCKS ? (COUNTS ? ((blk << 8) | mask8) : blk) : col;
                         const uint32_t bkt = (key << a.sub_log2) | ((uint32_t)r & ((1u << a.sub_log2) - 1u));
-                        a.pairs[pair_base + pair_used] = make_uint2((uint32_t)r, BLOCKS ? (key | (mask8 << 24)) : col);
+                        a.pairs[pair_base + pair_used] = make_uint2((uint32_t)r, BLOCKS ? (blk | (mask8 << 24)) : col);
                         atomicAdd(&a.bucket_cnt[bkt], 1u);
                         if (COUNTS && a.bucket_words) atomicAdd(&a.bucket_words[bkt], miss_need);
                     }
@@ -756,6 +758,11 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
 
 template <bool DEFER, uint32_t LPR_LOG2>
 static void launch_classify_counts(const QueryArgs &a, dim3 g, dim3 b, hipStream_t st) {
+    if (DEFER && a.block_pairs) {
+        hipLaunchKernelGGL((k_classify<DEFER, true, false, LPR_LOG2, DEFER>), g, b, 0, st, a);
+        hipLaunchKernelGGL((k_classify<DEFER, true, true, LPR_LOG2, DEFER>), g, b, 0, st, a);
+        return;
+    }
     hipLaunchKernelGGL((k_classify<DEFER, true, false, LPR_LOG2>), g, b, 0, st, a);
     hipLaunchKernelGGL((k_classify<DEFER, true, true, LPR_LOG2>), g, b, 0, st, a);  // the reads of >= 256 k-mers it queued
 }
@@ -961,20 +968,21 @@ __global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, cons
                                                         uint2 *sorted, uint4 *meta, const uint64_t *read_off,
                                                         const uint32_t *col_row, const uint32_t *words_off,
                                                         uint32_t *words_cur, uint32_t *miss_pos, uint32_t kmer_size,
-                                                        const uint32_t *owner, uint32_t *owner_sorted) {
+                                                        const uint32_t *owner, uint32_t *owner_sorted, uint32_t key_mode) {
     uint64_t n = *n_pairs_ptr;
     if (n > pair_cap) n = pair_cap;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint2 p = pairs[i];
         if (p.y == 0xffffffffu) continue;  // voided slot of a partially used reservation
-        const uint32_t key = col_row ? p.y : (p.y & 0xffffffu);  // (block mode: block | mask << 24)
+        // (block mode: p.y = block | mask << 24; keyed by the block, or — k-mer entries — by (block, mask))
+        const uint32_t key = key_mode == 0 ? p.y : (key_mode == 2 ? (((p.y & 0xffffffu) << 8) | (p.y >> 24)) : (p.y & 0xffffffu));
         const uint32_t bkt = (key << sub_log2) | (p.x & ((1u << sub_log2) - 1u));
         uint32_t pos = off[bkt] + atomicAdd(&cur[bkt], 1u);
         sorted[pos] = p;
         if (owner) owner_sorted[pos] = owner[i];
         if (meta) {
             uint64_t o0 = read_off[p.x], L = read_off[p.x + 1] - o0;
-            meta[pos] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)L, col_row ? col_row[p.y] : p.y);
+            meta[pos] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)L, key_mode == 0 ? col_row[p.y] : p.y);
             if (miss_pos) {  // thresholds < 1: the pair's miss words, ceil(n/64) of them, inside its bucket's range
                 const uint32_t words = (uint32_t)((L - kmer_size + 1 + 63) >> 6);
                 miss_pos[pos] = words_off[bkt] + atomicAdd(&words_cur[bkt], words);
@@ -985,10 +993,10 @@ __global__ void __launch_bounds__(256) k_bucket_scatter(const uint2 *pairs, cons
 void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs_ptr, uint64_t pair_cap,
                            const uint32_t *bucket_off, uint32_t *bucket_cur, uint32_t sub_log2, uint2 *sorted, uint4 *meta,
                            const uint64_t *read_off, const uint32_t *col_row, const uint32_t *words_off, uint32_t *words_cur,
-                           uint32_t *miss_pos, uint32_t kmer_size, const uint32_t *owner, uint32_t *owner_sorted, int blocks,
-                           hipStream_t st) {
+                           uint32_t *miss_pos, uint32_t kmer_size, const uint32_t *owner, uint32_t *owner_sorted, uint32_t key_mode,
+                           int blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, pairs, n_pairs_ptr, pair_cap, bucket_off, bucket_cur,
-                       sub_log2, sorted, meta, read_off, col_row, words_off, words_cur, miss_pos, kmer_size, owner, owner_sorted);
+                       sub_log2, sorted, meta, read_off, col_row, words_off, words_cur, miss_pos, kmer_size, owner, owner_sorted, key_mode);
 }
 
 // ---- K2 for bucketed survivors: L2-resident filter slices ------------------------------------------------------------
@@ -1259,63 +1267,81 @@ __global__ void __launch_bounds__(256) k_prefix_open(FinalizeArgs a, const uint4
         const uint32_t n = meta[e].z - a.hp.k + 1, pn = prefix_kmers(a.threshold, n, a.hp.k);
         if (pn == n) continue;  // everything was binned
         const uint64_t s0 = a.pair_kpos[e];
-        const uint32_t missing = count_miss_bytes(a.kmiss + kbase, s0, s0 + pn);
+        const uint32_t missing = count_miss_bytes(a.kmiss + (uint64_t)kbase * 16u, s0, s0 + pn);
         if (pn - missing < need_kmers(a.threshold, n)) atomicOr(&fail[e], 2u);  // undecided: the record kernel counts all k-mers
     }
 }
 void launch_prefix_open(const FinalizeArgs &a, const uint4 *meta, const uint32_t *n_pairs_ptr, uint32_t *fail, hipStream_t st) {
     hipLaunchKernelGGL(k_prefix_open, dim3(2048), dim3(256), 0, st, a, meta, n_pairs_ptr, fail);
 }
+// One block per column (block mode with k-mer entries: per block of 8 leaves — its pairs lie in up to 256 buckets, one per
+// candidate mask; the chunks of a column are numbered contiguously and never mix two masks).
 __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
     __shared__ unsigned long long s_sum;
-    __shared__ uint32_t s_chunk0;
-    const uint32_t c = blockIdx.x;
-    const uint32_t lo = a.bucket_off[c << a.sub_log2], hi = a.bucket_off[(c + 1) << a.sub_log2];
-    const uint32_t cl = a.chunk_log2;
-    const uint32_t n_ch = (hi - lo + (1u << cl) - 1u) >> cl;
+    __shared__ uint32_t s_chunk0, s_w[4];
+    const uint32_t c = blockIdx.x, cl = a.chunk_log2;
+    const uint32_t n_sub = (a.blocks && a.counts) ? 256u : 1u;  // buckets of this column
+    // chunks of the column = sum over its buckets
+    uint32_t mine = 0;
+    if (threadIdx.x < n_sub) {
+        const uint32_t bk = c * n_sub + threadIdx.x;
+        mine = (a.bucket_off[(bk + 1) << a.sub_log2] - a.bucket_off[bk << a.sub_log2] + (1u << cl) - 1u) >> cl;
+    }
+    uint32_t tot = mine;
+    for (int d = 32; d > 0; d >>= 1) tot += __shfl_down(tot, d);
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    const uint32_t n_col = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     if (threadIdx.x == 0) {
-        s_chunk0 = n_ch ? atomicAdd(a.n_chunks, n_ch) : 0u;
-        a.leaf_chunk0[c] = n_ch ? s_chunk0 : 0xffffffffu;
+        s_chunk0 = n_col ? atomicAdd(a.n_chunks, n_col) : 0u;
+        a.leaf_chunk0[c] = n_col ? s_chunk0 : 0xffffffffu;
     }
     __syncthreads();
-    const uint32_t chunk0 = s_chunk0;
-    for (uint32_t ci = 0; ci < n_ch; ++ci) {
-        const uint32_t first = lo + (ci << cl), n = (hi - first) < (1u << cl) ? hi - first : (1u << cl);
-        if (threadIdx.x == 0) s_sum = 0;
-        __syncthreads();
-        unsigned long long kmers = 0;
-        const uint32_t chunk = chunk0 + ci;
-        for (uint32_t e = first + threadIdx.x; e < first + n; e += blockDim.x) {
-            const uint32_t n_e = a.meta[e].z - a.hp.k + 1;
-            kmers += a.counts ? prefix_kmers(a.threshold, n_e, a.hp.k) : n_e;
-            a.pair_chunk[e] = chunk < a.max_chunks ? chunk : 0xffffffffu;
+    uint32_t chunk = s_chunk0;
+    for (uint32_t sb = 0; sb < n_sub; ++sb) {
+        const uint32_t bk = c * n_sub + sb;
+        const uint32_t lo = a.bucket_off[bk << a.sub_log2], hi = a.bucket_off[(bk + 1) << a.sub_log2];
+        const uint32_t n_ch = (hi - lo + (1u << cl) - 1u) >> cl;
+        for (uint32_t ci = 0; ci < n_ch; ++ci, ++chunk) {
+            const uint32_t first = lo + (ci << cl), n = (hi - first) < (1u << cl) ? hi - first : (1u << cl);
+            if (threadIdx.x == 0) s_sum = 0;
+            __syncthreads();
+            unsigned long long kmers = 0;
+            for (uint32_t e = first + threadIdx.x; e < first + n; e += blockDim.x) {
+                const uint32_t n_e = a.meta[e].z - a.hp.k + 1;
+                kmers += (a.counts && !a.blocks) ? prefix_kmers(a.threshold, n_e, a.hp.k) : n_e;  // (block mode bins every k-mer)
+                a.pair_chunk[e] = chunk < a.max_chunks ? chunk : 0xffffffffu;
+            }
+            for (int d = 32; d > 0; d >>= 1) kmers += __shfl_down(kmers, d);
+            if (lane_id() == 0 && kmers) atomicAdd(&s_sum, kmers);
+            __syncthreads();
+            if (threadIdx.x == 0 && chunk < a.max_chunks) {
+                // mean probes per tile + 8 standard deviations of a Poisson count + slack (anything beyond falls back) + the
+                // padding of k_tile_bin's runs (up to 3 entries per round: a round brings >= 96 probes per tile, or 32 pairs)
+                unsigned long long mean = (s_sum * a.hp.num_hashes + a.n_tiles - 1) / a.n_tiles;
+                const unsigned long long dev = (unsigned long long)(8.0f * sqrtf((float)mean)) + 64;
+                uint32_t cap = (uint32_t)((mean + dev + (mean >> 5) + 3 * ((n + 31) / 32 + 2) + 31) & ~31ull);
+                unsigned long long need = (unsigned long long)cap * a.n_tiles;
+                // (where the chunk's buckets go — pass and position in the reused buffer — is decided by k_tile_assign)
+                const bool fits = need <= a.entry_cap;
+                ChunkDesc dsc;
+                dsc.row = a.blocks ? (a.meta[first].w & 0xffffffu) : a.meta[first].w;
+                dsc.first = first;
+                dsc.n = n;
+                dsc.cap = fits ? cap : 0u;   // a single chunk larger than the whole buffer: its pairs take the fallback
+                dsc.base = 0;
+                dsc.leaf = c;
+                dsc.pass = 0;
+                dsc.kbase = 0;   // (placed by k_tile_assign)
+                // one miss byte per k-mer of the chunk (block mode: eight, one per leaf of the block), in 16-byte units
+                dsc.kwords = a.counts ? (uint32_t)(((a.blocks ? s_sum * 8 : s_sum) + 15) >> 4) : 0u;
+                dsc.mask = a.blocks ? a.meta[first].w >> 24 : 0u;  // (the mask all pairs of the chunk share)
+                dsc.pad_ = 0;
+                if (a.counts && s_sum >= (1ull << 28)) dsc.cap = 0;
+                a.chunks[chunk] = dsc;
+            }
+            __syncthreads();
         }
-        for (int d = 32; d > 0; d >>= 1) kmers += __shfl_down(kmers, d);
-        if (lane_id() == 0 && kmers) atomicAdd(&s_sum, kmers);
-        __syncthreads();
-        if (threadIdx.x == 0 && chunk < a.max_chunks) {
-            // mean probes per tile + 8 standard deviations of a Poisson count + slack (anything beyond falls back) + the
-            // padding of k_tile_bin's runs (up to 3 entries per round: a round brings >= 96 probes per tile, or 32 pairs)
-            unsigned long long mean = (s_sum * a.hp.num_hashes + a.n_tiles - 1) / a.n_tiles;
-            const unsigned long long dev = (unsigned long long)(8.0f * sqrtf((float)mean)) + 64;
-            uint32_t cap = (uint32_t)((mean + dev + (mean >> 5) + 3 * ((n + 31) / 32 + 2) + 31) & ~31ull);
-            unsigned long long need = (unsigned long long)cap * a.n_tiles;
-            // (where the chunk's buckets go — pass and position in the reused buffer — is decided by k_tile_assign)
-            const bool fits = need <= a.entry_cap;
-            ChunkDesc dsc;
-            dsc.row = a.blocks ? (a.meta[first].w & 0xffffffu) : a.meta[first].w;
-            dsc.first = first;
-            dsc.n = n;
-            dsc.cap = fits ? cap : 0u;   // a single chunk larger than the whole buffer: its pairs take the fallback
-            dsc.base = 0;
-            dsc.leaf = c;
-            dsc.pass = 0;
-            dsc.kbase = 0;   // (placed by k_tile_assign)
-            dsc.kwords = a.counts ? (uint32_t)((s_sum + 15) >> 4) : 0u;  // one miss byte per k-mer of the chunk, in 16-byte units
-            if (a.counts && s_sum >= (1ull << 31)) dsc.cap = 0;
-            a.chunks[chunk] = dsc;
-        }
-        __syncthreads();
     }
 }
 // The bucket space is virtual: pass = position / entry_cap, place in the (reused) buffer = position % entry_cap.
@@ -1333,19 +1359,19 @@ __global__ void __launch_bounds__(64) k_tile_assign(TileArgs a) {
         for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
             const uint32_t c = c0 + lane;
             const bool have = c < n_chunks && a.chunks[c].cap != 0;
-            const unsigned long long need = have ? (unsigned long long)a.chunks[c].kwords * 16u : 0u;
+            const unsigned long long need = have ? (unsigned long long)a.chunks[c].kwords : 0u;  // (16-byte units)
             unsigned long long incl = need;
             for (int dd = 1; dd < 64; dd <<= 1) {
                 const unsigned long long o = __shfl_up(incl, dd);
                 if ((int)lane >= dd) incl += o;
             }
             if (have) {
-                if (run + incl <= a.kmiss_cap) a.chunks[c].kbase = (uint32_t)(run + incl - need);
+                if ((run + incl) * 16u <= a.kmiss_cap) a.chunks[c].kbase = (uint32_t)(run + incl - need);
                 else a.chunks[c].cap = 0;
             }
             run += __shfl(incl, 63);
         }
-        if (lane == 0) *a.kmiss_used = run < a.kmiss_cap ? run : a.kmiss_cap;  // (k_zero16 clears that much)
+        if (lane == 0) *a.kmiss_used = run * 16u < a.kmiss_cap ? run * 16u : a.kmiss_cap;  // (k_zero16 clears that many bytes)
     }
     unsigned long long total = 0;
     for (uint32_t c = lane; c < n_chunks; c += 64) total += (unsigned long long)a.chunks[c].cap * a.n_tiles;
@@ -1407,6 +1433,8 @@ void launch_tile_plan(const TileArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(k_tile_plan, dim3(a.n_leaves), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_tile_assign, dim3(1), dim3(64), 0, st, a);
     if (a.counts) hipLaunchKernelGGL(k_zero16, dim3(2048), dim3(256), 0, st, reinterpret_cast<uint4 *>(a.kmiss), a.kmiss_used);
+    // (block mode: the per-k-mer "no leaf of the block has it" bytes, one per 8 miss bytes — cleared whole, they are small)
+    if (a.counts && a.blocks) (void)hipMemsetAsync(a.kall, 0, (a.kmiss_cap >> 3) + 16, st);
 }
 
 // k_tile_bin: a block takes whole chunks from a queue and bins every probe of the chunk's pairs by filter tile.
@@ -1437,12 +1465,12 @@ __device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, in
 // [candidate mask:8][pair:7][byte offset:17] against the byte-per-index table of a block of 8 leaves.
 template <uint32_t BIN_WAVES, uint32_t BIN_CAP, uint32_t MODE>
 __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
-    constexpr bool COUNTS = MODE == 1, BLK = MODE == 2;
+    constexpr bool COUNTS = MODE == 1 || MODE == 3, BLK = MODE == 2;  // (MODE 3: k-mer entries against block tables, no prefix)
     // COUNTS (thresholds < 1): an entry is [round tag:2][flattened k-mer of the round:11][offset in a 64 KiB tile:19]; the
     // tags are ORed in at flush time (position in the 16-byte vector -> two bits of the round's number), runs are padded
     // with copies of their last entry (testing a probe twice changes nothing), and per round the chunk position of its
     // first k-mer goes to round_k0, per pair the position of its first k-mer to pair_kpos.
-    constexpr uint32_t TL = COUNTS ? TILE_LOG2_COUNTS : (BLK ? TILE_LOG2_BLOCK : TILE_LOG2);
+    constexpr uint32_t TL = MODE == 1 ? TILE_LOG2_COUNTS : (MODE >= 2 ? TILE_LOG2_BLOCK : TILE_LOG2);
     constexpr uint32_t BIN_STRIDE = BIN_CAP + 4;  // rows stay 16-byte aligned; room for the padding of a full bin
     constexpr uint32_t WPI = 2;                    // windows per wave and iteration
     const uint32_t NT = (a.n_tiles + 63u) & ~63u;  // tiles, rounded up
@@ -1490,7 +1518,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
             r.koff = koff;
             const bool cand = lane < ROUND_PAIRS && p + lane < dsc.n;
             // (k-mer entries: only the prefix of the read's k-mers that decides nearly every pair, see prefix_kmers)
-            const uint32_t n_all = cand ? m.z - k + 1u : 0u, n_bin = (COUNTS && cand) ? prefix_kmers(a.threshold, n_all, k) : n_all;
+            const uint32_t n_all = cand ? m.z - k + 1u : 0u, n_bin = (MODE == 1 && cand) ? prefix_kmers(a.threshold, n_all, k) : n_all;
             const unsigned long long n64 = cand ? (unsigned long long)n_bin - (lane == 0 ? koff : 0ull) : 0ull;
             const uint32_t n_l = (uint32_t)(n64 > KB ? KB + 1u : n64);  // (more than the budget is all the same)
             uint32_t incl = n_l;
@@ -1696,8 +1724,10 @@ static void launch_tile_bin_shape(const TileArgs &a, int blocks, size_t lds, hip
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_bin<W, CAP, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     }
-    if (a.counts) hipLaunchKernelGGL((k_tile_bin<W, CAP, 1>), dim3(blocks), dim3(W * 64), lds, st, a);
+    if (a.counts && a.blocks) hipLaunchKernelGGL((k_tile_bin<W, CAP, 3>), dim3(blocks), dim3(W * 64), lds, st, a);
+    else if (a.counts) hipLaunchKernelGGL((k_tile_bin<W, CAP, 1>), dim3(blocks), dim3(W * 64), lds, st, a);
     else if (a.blocks) hipLaunchKernelGGL((k_tile_bin<W, CAP, 2>), dim3(blocks), dim3(W * 64), lds, st, a);
     else hipLaunchKernelGGL((k_tile_bin<W, CAP, 0>), dim3(blocks), dim3(W * 64), lds, st, a);
 }
@@ -1736,15 +1766,21 @@ constexpr uint32_t TEST_GROUP = 32;  // chunks of a leaf whose buckets are strea
 // byte per (pair, leaf)), reported once per block and task through the LDS bitmap.
 template <uint32_t MODE>
 __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
-    constexpr bool COUNTS = MODE == 1, BLK = MODE == 2;
-    constexpr uint32_t TL = COUNTS ? TILE_LOG2_COUNTS : (BLK ? TILE_LOG2_BLOCK : TILE_LOG2);
-    constexpr uint32_t TILE_BYTES = BLK ? (1u << TL) : (1u << (TL - 3));
+    // MODE 3 (block mode at thresholds < 1): k-mer entries against the block's byte table; the candidate mask comes with the
+    // chunk (buckets are keyed by (block, mask)); a candidate whose bit is 0 gets the k-mer's miss byte of that leaf set.
+    constexpr bool COUNTS = MODE == 1 || MODE == 3, BLK = MODE == 2, BLKC = MODE == 3;
+    constexpr uint32_t TL = MODE == 1 ? TILE_LOG2_COUNTS : (MODE >= 2 ? TILE_LOG2_BLOCK : TILE_LOG2);
+    constexpr uint32_t TILE_BYTES = MODE >= 2 ? (1u << TL) : (1u << (TL - 3));
     constexpr uint32_t TV = TILE_BYTES / 8192u;        // 8-byte loads per thread and tile
     constexpr uint32_t CL = BLK ? CHUNK_PAIRS_LOG2_BLOCK : CHUNK_PAIRS_LOG2;  // pairs per chunk (LDS bitmap of reported failures)
-    constexpr uint32_t TG = BLK ? 64 : TEST_GROUP;  // chunks per unit (block mode: chunks of 128 pairs, a unit should still bring >= 16 k entries)
+    // chunks per unit (block mode: chunks of 128 pairs, a unit should still bring >= 16 k entries; MODE 3: the round tables
+    // of 16 chunks are what fits beside the 128 KiB tile)
+    constexpr uint32_t TG = BLK ? 64 : (BLKC ? 16 : TEST_GROUP);
     constexpr uint32_t RK = COUNTS ? MAX_ROUNDS : 1u;
     extern __shared__ uint32_t s_tile[];  // 2^TL bits
-    __shared__ uint32_t s_pref[2][TG + 1], s_first[2][TG], s_misc[2][2], s_kbase[2][TG];
+    __shared__ uint32_t s_pref[2][TG + 1], s_first[2][TG], s_misc[2][2], s_kbase[2][TG], s_mask[2][TG];
+    const uint32_t n_cols = a.n_leaves;
+    auto col_of = [&](uint32_t li) { return li; };
     // failures this block already reported: a bit per pair of the group (MODE 0), per (pair, leaf of the block) (MODE 2)
     __shared__ uint32_t s_failed[COUNTS ? 1 : (BLK ? (TG << (CL - 2)) : (TG << (CL - 5)))];
     constexpr uint32_t N_FAILED = COUNTS ? 0 : (BLK ? (TG << (CL - 2)) : (TG << (CL - 5)));
@@ -1752,11 +1788,11 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     __shared__ unsigned long long s_base[2][TG];
     const uint32_t tile_words = TILE_BYTES / 4u;
     const uint64_t n_words32 = a.n_words * 2;  // (block mode: n_words = bytes / 8 of one block's table)
-    const uint64_t n_tasks = (uint64_t)a.n_leaves * a.n_tiles;
+    const uint64_t n_tasks = (uint64_t)n_cols * a.n_tiles;
     const uint32_t n_chunks = *a.n_chunks < a.max_chunks ? *a.n_chunks : a.max_chunks;
     // next task of this block at or after `task` whose column has pairs at all (block-uniform)
     auto valid_task = [&](uint64_t task) {
-        while (task < n_tasks && a.leaf_chunk0[(uint32_t)(task / a.n_tiles)] == 0xffffffffu) task += gridDim.x;
+        while (task < n_tasks && a.leaf_chunk0[col_of((uint32_t)(task / a.n_tiles))] == 0xffffffffu) task += gridDim.x;
         return task;
     };
     // The buckets (this tile's) of up to 32 chunks of the column starting at chunk g0, described in LDS: they are streamed
@@ -1777,6 +1813,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
             s_pref[buf][i + 1] = incl;
             s_first[buf][i] = dsc.first;
             s_kbase[buf][i] = dsc.kbase;
+            s_mask[buf][i] = dsc.mask;
             s_base[buf][i] = dsc.base + (uint64_t)t * dsc.cap;
         }
         const uint64_t mm = ballot64(mine);
@@ -1788,7 +1825,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     // the column's tile: words [t * tile_words, ...) of its filter row (zero beyond the filter's end); filter rows are only
     // 8-byte aligned: 8-byte loads, all of a thread in flight
     auto tile_loads = [&](uint32_t leaf, uint32_t t, uint2 (&v)[TV]) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)(BLK ? leaf : a.col_row[leaf]) * a.n_words);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.bits + (uint64_t)((BLK || BLKC) ? leaf : a.col_row[leaf]) * a.n_words);
         const uint64_t w0 = (uint64_t)t * tile_words;
 #pragma unroll
         for (uint32_t u = 0; u < TV; ++u) {
@@ -1804,21 +1841,22 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     };
     // COUNTS: the round_k0 rows of the 32 chunks from g0 on: 32 threads per chunk, 8 rounds per thread (rounds the chunk
     // did not have — and chunks of other columns — are never looked up)
+    constexpr uint32_t RK_TPC = 1024u / TG, RK_V = TG / 16u;  // threads per chunk; 16-byte loads per thread (4 rounds each)
     auto rk_loads = [&](uint32_t g0, uint4 (&rk)[2]) {
-        const uint32_t c = g0 + (threadIdx.x >> 5), r0 = (threadIdx.x & 31u) * 8u;
+        const uint32_t c = g0 + threadIdx.x / RK_TPC, r0 = (threadIdx.x % RK_TPC) * 4u * RK_V;
         rk[0] = rk[1] = make_uint4(0, 0, 0, 0);
         if (COUNTS && c < n_chunks && r0 < a.n_rounds[c]) {
             const uint4 *src = reinterpret_cast<const uint4 *>(a.round_k0 + (uint64_t)c * MAX_ROUNDS + r0);
             rk[0] = src[0];
-            rk[1] = src[1];
+            if (RK_V > 1) rk[1] = src[1];
         }
     };
     auto rk_store = [&](const uint4 (&rk)[2]) {
         if (COUNTS) {
-            static_assert(!COUNTS || TG == 32, "32 threads per chunk fetch the round tables");
-            uint4 *dst = reinterpret_cast<uint4 *>(&s_rk0[threadIdx.x >> 5][(threadIdx.x & 31u) * 8u]);
+            static_assert(!COUNTS || TG == 32 || TG == 16, "1024 threads fetch 256 rounds of TG chunks in one or two 16-byte loads each");
+            uint4 *dst = reinterpret_cast<uint4 *>(&s_rk0[threadIdx.x / RK_TPC][(threadIdx.x % RK_TPC) * 4u * RK_V]);
             dst[0] = rk[0];
-            dst[1] = rk[1];
+            if (RK_V > 1) dst[1] = rk[1];
         }
     };
     // 16 entries in flight per thread as four 16-byte loads (buckets start on 128-byte boundaries, their fill marks are
@@ -1847,7 +1885,29 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
 #pragma unroll
             for (uint32_t u = 0; u < TEST_LOADS; ++u) {
                 const uint32_t ev[4] = {en[u].x, en[u].y, en[u].z, en[u].w};
-                if (COUNTS) {
+                if (BLKC) {
+                    if (!have[u]) continue;
+                    const uint32_t mk = s_mask[buf][cidx[u]];
+                    uint32_t bad[4], any = 0;
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; ++c) {
+                        bad[c] = mk & ~(uint32_t)reinterpret_cast<const uint8_t *>(s_tile)[ev[c] & ((1u << TL) - 1u)];
+                        any |= bad[c];
+                    }
+                    if (any) {
+                        const uint32_t rho = (ev[0] >> 30) | ((ev[1] >> 30) << 2) | ((ev[2] >> 30) << 4) | ((ev[3] >> 30) << 6);
+                        const uint64_t k0 = (uint64_t)s_kbase[buf][cidx[u]] * 16u + (uint64_t)s_rk0[cidx[u]][rho] * 8u;
+#pragma unroll
+                        for (uint32_t c = 0; c < 4; ++c) {  // plain idempotent byte stores
+                            if (!bad[c]) continue;
+                            const uint64_t kq = (k0 >> 3) + ((ev[c] >> TL) & ((1u << ROUND_KMERS_LOG2) - 1u));  // the k-mer's index
+                            // a k-mer over a sequencing error is in none of the block's leaves: ONE byte says so for all candidates
+                            if (bad[c] == mk) a.kall[kq] = 1;
+                            else
+                                for (uint32_t m = bad[c]; m; m &= m - 1u) a.kmiss[kq * 8u + (uint32_t)__ffs((int)m) - 1u] = 1;  // a byte per (k-mer, leaf)
+                        }
+                    }
+                } else if (COUNTS) {
                     if (!have[u]) continue;
                     uint32_t bad = 0;
 #pragma unroll
@@ -1863,7 +1923,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
                             if (!((bad >> c) & 1u)) continue;
                             // a plain byte store: idempotent, no read-modify-write (device-scope atomics are performed at
                             // the memory side on this part — 2.7 G/s when a k-mer over a sequencing error fails in ten tiles)
-                            a.kmiss[(uint64_t)wb + kb + ((ev[c] >> TL) & ((1u << ROUND_KMERS_LOG2) - 1u))] = 1;
+                            a.kmiss[(uint64_t)wb * 16u + kb + ((ev[c] >> TL) & ((1u << ROUND_KMERS_LOG2) - 1u))] = 1;
                         }
                     }
                 } else if (BLK) {
@@ -1903,9 +1963,9 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     // chunks: fetching every group's descriptors where they are needed cost 9 of 16 ms.)
     uint64_t task = valid_task(blockIdx.x);
     if (task >= n_tasks) return;
-    uint32_t buf = 0, g0 = a.leaf_chunk0[(uint32_t)(task / a.n_tiles)];
+    uint32_t buf = 0, g0 = a.leaf_chunk0[col_of((uint32_t)(task / a.n_tiles))];
     {
-        const uint32_t leaf = (uint32_t)(task / a.n_tiles), t = (uint32_t)(task % a.n_tiles);
+        const uint32_t leaf = col_of((uint32_t)(task / a.n_tiles)), t = (uint32_t)(task % a.n_tiles);
         uint2 v[TV];
         uint4 rk[2];
         tile_loads(leaf, t, v);
@@ -1921,7 +1981,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
         const bool more = s_misc[buf][0] == TG;  // (block-uniform)
         const uint64_t ntask = more ? task : valid_task(task + gridDim.x);
         const bool have_n = ntask < n_tasks;
-        const uint32_t nleaf = have_n ? (uint32_t)(ntask / a.n_tiles) : 0u, nt = have_n ? (uint32_t)(ntask % a.n_tiles) : 0u;
+        const uint32_t nleaf = have_n ? col_of((uint32_t)(ntask / a.n_tiles)) : 0u, nt = have_n ? (uint32_t)(ntask % a.n_tiles) : 0u;
         const uint32_t ng0 = more ? g0 + TG : (have_n ? a.leaf_chunk0[nleaf] : 0u);
         uint2 vn[TV];
         uint4 rkn[2];
@@ -1948,9 +2008,11 @@ void launch_tile_test(const TileArgs &a, int blocks, hipStream_t st) {
         // (static LDS of the k-mer-entry build: the 32 KiB of round_k0 rows; static + dynamic must stay within the CU's 160 KiB)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << (TILE_LOG2_COUNTS - 3));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << TILE_LOG2_BLOCK);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_test<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 << TILE_LOG2_BLOCK);
     }
     const dim3 g((blocks + 1) / 2), b(1024);
-    if (a.counts) hipLaunchKernelGGL(k_tile_test<1>, g, b, (size_t)(1u << (TILE_LOG2_COUNTS - 3)), st, a);
+    if (a.counts && a.blocks) hipLaunchKernelGGL(k_tile_test<3>, g, b, (size_t)(1u << TILE_LOG2_BLOCK), st, a);
+    else if (a.counts) hipLaunchKernelGGL(k_tile_test<1>, g, b, (size_t)(1u << (TILE_LOG2_COUNTS - 3)), st, a);
     else if (a.blocks) hipLaunchKernelGGL(k_tile_test<2>, g, b, (size_t)(1u << TILE_LOG2_BLOCK), st, a);
     else hipLaunchKernelGGL(k_tile_test<0>, g, b, (size_t)(1u << (TILE_LOG2 - 3)), st, a);
 }
@@ -2073,6 +2135,46 @@ void launch_block_fallback(const QueryArgs &a, const uint2 *sorted, const uint32
     hipLaunchKernelGGL(k_block_fallback, dim3(1024), dim3(256), 0, st, a, sorted, n_pairs_ptr, fail, failb, pair_chunk, chunks, launched_passes);
 }
 
+// Block mode with k-mer entries: the miss bytes of the binned pairs decide their candidates.  A wave per pair, lanes =
+// k-mers: the 8 miss bytes of 64 k-mers are one coalesced read, a ballot per leaf counts them; a candidate with fewer than
+// `need` contained k-mers gets its failure byte (what k_finalize reads).  Pairs that were not binned are left to
+// k_block_fallback.
+__global__ void __launch_bounds__(256) k_block_count(FinalizeArgs a, const uint32_t *n_pairs_ptr, uint8_t *failb) {
+    const uint32_t lane = lane_id(), n_pairs = *n_pairs_ptr;
+    const uint64_t gw = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), nw = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (uint64_t e = gw; e < n_pairs; e += nw) {
+        uint32_t kb16 = 0;
+        if (!pair_in_chunk(a.fail, a.pair_chunk, a.chunks, a.launched_passes, (uint32_t)e, kb16)) continue;  // (wave-uniform)
+        const uint2 p = a.sorted[e];
+        const uint64_t o0 = a.off[p.x], L = a.off[p.x + 1] - o0, n = L - a.hp.k + 1, need = need_kmers(a.threshold, n);
+        const uint64_t q0 = (uint64_t)kb16 * 2u + a.pair_kpos[e];  // first k-mer of the pair
+        const uint2 *km = reinterpret_cast<const uint2 *>(a.kmiss) + q0;
+        uint32_t miss[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint64_t k0 = 0; k0 < n; k0 += 64) {
+            const uint64_t kk = k0 + lane;
+            uint2 w = make_uint2(0, 0);
+            if (kk < n) {
+                w = km[kk];
+                if (a.kall[q0 + kk]) w = make_uint2(0x01010101u, 0x01010101u);  // the k-mer is in no candidate leaf of the block
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                miss[j] += (uint32_t)__popcll(ballot64((w.x >> (8u * j)) & 0xffu));
+                miss[4 + j] += (uint32_t)__popcll(ballot64((w.y >> (8u * j)) & 0xffu));
+            }
+        }
+        if (lane < 8 && ((p.y >> (24 + lane)) & 1u)) {
+            uint32_t mj = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) mj = lane == j ? miss[j] : mj;
+            if (n - mj < need) failb[(e << 3) + lane] = 1;
+        }
+    }
+}
+void launch_block_count(const FinalizeArgs &a, const uint32_t *n_pairs_ptr, uint8_t *failb, hipStream_t st) {
+    hipLaunchKernelGGL(k_block_count, dim3(2048), dim3(256), 0, st, a, n_pairs_ptr, failb);
+}
+
 __global__ void __launch_bounds__(256) k_block_guards(QueryArgs a, const uint2 *sorted, const uint32_t *n_pairs_ptr, uint8_t *failb) {
     __shared__ BlockLds lds;
     fill_complement(lds.comp);
@@ -2127,8 +2229,10 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
             if (threadIdx.x == 0) s_bytes = 0;
             __syncthreads();
             unsigned long long bytes = 0;
+            uint32_t blk = 0xffffffffu;  // the block of this bucket's pairs (buckets by block, or by (block, mask))
             for (uint32_t e = a.bucket_off[c << a.sub_log2] + threadIdx.x; e < a.bucket_off[(c + 1) << a.sub_log2]; e += blockDim.x) {
                 const uint2 p = a.sorted[e];
+                blk = p.y & 0xffffffu;
                 const uint2 fb = *reinterpret_cast<const uint2 *>(a.failb + ((uint64_t)e << 3));
                 uint32_t failed = 0;
 #pragma unroll
@@ -2136,11 +2240,11 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
                     failed |= ((fb.x >> (8u * j)) & 0xffu) ? 1u << j : 0u;
                     failed |= ((fb.y >> (8u * j)) & 0xffu) ? 16u << j : 0u;
                 }
-                const uint64_t o0 = a.off[p.x], L = a.off[p.x + 1] - o0, n = L - a.hp.k + 1;
+                const uint64_t o0 = a.off[p.x], L = a.off[p.x + 1] - o0, n = L - a.hp.k + 1, need = need_kmers(a.threshold, n);
                 for (uint32_t m = (p.y >> 24) & ~failed; m; m &= m - 1u) {
                     const uint32_t j = (uint32_t)__ffs((int)m) - 1u;
                     atomicAdd(&s_leaf[j], 1u);
-                    bytes += n * a.hp.num_hashes * 32ull;
+                    bytes += need * a.hp.num_hashes * 32ull;
                     if (a.hit_pairs) {
                         unsigned long long pos = atomicAdd(a.hit_cursor, 1ull);
                         if (pos < a.hit_cap) a.hit_pairs[pos] = make_uint2(p.x, ((p.y & 0xffffffu) << BLOCK_LEAVES_LOG2) + j);
@@ -2150,8 +2254,11 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
             for (int d = 32; d > 0; d >>= 1) bytes += __shfl_down(bytes, d);
             if (lane_id() == 0 && bytes) atomicAdd(&s_bytes, bytes);
             __syncthreads();
+            __shared__ uint32_t s_blk;
+            if (blk != 0xffffffffu) s_blk = blk;  // (every pair of the bucket names the same block)
+            __syncthreads();
             if (threadIdx.x < 8 && s_leaf[threadIdx.x]) {
-                atomicAdd(&a.counts[(c << BLOCK_LEAVES_LOG2) + threadIdx.x], (unsigned long long)s_leaf[threadIdx.x]);
+                atomicAdd(&a.counts[(s_blk << BLOCK_LEAVES_LOG2) + threadIdx.x], (unsigned long long)s_leaf[threadIdx.x]);
                 atomicAdd(&a.stats[ST_HITS], (unsigned long long)s_leaf[threadIdx.x]);
             }
             if (threadIdx.x == 0 && s_bytes) atomicAdd(&a.stats[ST_ALG_BYTES], s_bytes);
@@ -2179,7 +2286,7 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
                 if (in_chunk) {  // the binned prefix of the read's k-mers (k_prefix_open saw to it that it decides the pair)
                     n_seen = prefix_kmers(a.threshold, (uint32_t)n, a.hp.k);
                     const uint64_t s0 = a.pair_kpos[e];
-                    missing = count_miss_bytes(a.kmiss + kbase, s0, s0 + n_seen);
+                    missing = count_miss_bytes(a.kmiss + (uint64_t)kbase * 16u, s0, s0 + n_seen);
                 } else {
                     const unsigned long long *mw = a.miss_words + a.miss_pos[e];
                     const uint32_t nw = (uint32_t)((n + 63) >> 6);
@@ -2222,7 +2329,9 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
     }
 }
 void launch_finalize(const FinalizeArgs &a, hipStream_t st) {
-    uint32_t blocks = a.c1 - a.c0 < 2048u ? a.c1 - a.c0 : 2048u;
+    // (block mode with k-mer entries: the buckets that hold nearly all pairs — mask 0xff of every block — are 256 apart:
+    // a grid of 2048 would hand them all to 8 blocks; a block per bucket up to 2^20 of them)
+    uint32_t blocks = a.c1 - a.c0 < (a.failb ? (1u << 20) : 2048u) ? a.c1 - a.c0 : (a.failb ? (1u << 20) : 2048u);
     if (a.c1 <= a.c0) return;
     hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, st, a);
 }

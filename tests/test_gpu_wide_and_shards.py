@@ -286,8 +286,8 @@ def test_family_workload_parity_300k_reads(gpu):
             offs, leaves = gt.query_packed(seq, off, thr, want_hits=True)
             st = gt.last_stats()
             assert st.path == 1
-            # at threshold 1 the calls after the first know that reads pass several leaves: block mode
-            assert st.tile_mode == (2 if thr == 1.0 and call > 0 else 1), (thr, call, st.tile_mode)
+            # every call after the very first knows that reads pass several leaves: block mode (at 0.6 with k-mer entries)
+            assert st.tile_mode == (1 if thr == 1.0 and call == 0 else 2), (thr, call, st.tile_mode)
             assert gt.get_leaf_counts() == ot.leaf_counts(), (thr, call)
             got = np.stack([np.repeat(np.arange(n_reads), np.diff(offs).astype(np.int64)), leaves.astype(np.int64)], 1)
             assert np.array_equal(got, want), (thr, call)
@@ -319,9 +319,19 @@ def test_block_mode_forced(gpu, n_genomes, k, nbits, h):
         finally:
             for key in env:
                 gt.set_option(key, None)
-    # thresholds below 1 keep the pair pipeline; PFQ_BLOCK=0 forbids block mode
-    assert check_query(gt, ot, reads, 0.5, path=1).tile_mode == 1
+    # thresholds below 1: k-mer entries against the block tables, buckets by (block, mask)
+    for env in ({}, {"PFQ_TILE_ENTRIES": "200000"}, {"PFQ_TILE_ENTRIES": "3000"}, {"PFQ_TILE_GB": "0"}):
+        for key, val in env.items():
+            gt.set_option(key, val)
+        try:
+            for thr in (0.5, 0.3, 0.9):
+                assert check_query(gt, ot, reads, thr, path=1).tile_mode == 2, (env, thr)
+        finally:
+            for key in env:
+                gt.set_option(key, None)
+    # PFQ_BLOCK=0 forbids block mode
     gt.set_option("PFQ_BLOCK", "0")
+    assert check_query(gt, ot, reads, 0.5, path=1).tile_mode == 1
     assert check_query(gt, ot, reads, 1.0, path=1).tile_mode == 1
     gt.close()
 
@@ -335,6 +345,7 @@ def test_prefix_certificates_and_round_overflow(gpu):
     genomes = [rand_dna(3000) for _ in range(12)]
     ot, ids = oracle_tree(genomes, k, nbits, h)
     gt = gpu_tree(genomes, ids, k, nbits, h)
+    gt.set_option("PFQ_BLOCK", "0")   # (the pair pipeline is what this test is about)
     acgt = b"ACGT"
 
     def mutate(read, positions):

@@ -26,6 +26,9 @@ fam8) run fam8 PFQ_BENCH_FAMILY=8 -- ;;
 fam8d0) run fam8d0 PFQ_BENCH_FAMILY=8 PFQ_BENCH_DIVERGENCE=0 -- ;;
 t1blk) run t1blk PFQ_BLOCK=1 -- ;;
 fam8t03) run fam8t03 PFQ_BENCH_FAMILY=8 -- --threshold 0.3 ;;
+fam8t03e) run fam8t03e PFQ_BENCH_FAMILY=8 PFQ_BENCH_READ_ERRORS=0.01 -- --threshold 0.3 ;;
+fam8t07e) run fam8t07e PFQ_BENCH_FAMILY=8 PFQ_BENCH_READ_ERRORS=0.01 -- --threshold 0.7 ;;
+fam4t03) run fam4t03 PFQ_BENCH_FAMILY=4 -- --threshold 0.3 ;;
 l64) run l64 X=1 -- --leaves 64 ;;
 l2048) run l2048 X=1 -- --leaves 2048 ;;
 l4096) run l4096 X=1 -- --leaves 4096 ;;
