@@ -190,7 +190,7 @@ typedef struct pfq_stats {
     uint32_t tile_mode;         /* 1: certificates tested out of LDS tiles (k_tile_*), k_verify_rec only as fallback
                                  * (thresholds < 1: entries name k-mers, the passes leave per-chunk miss bytes);
                                  * 2: block mode — pairs are (read, block of 8 leaves, candidate mask), one entry tests a probe for
-                                 * all candidates of the block (chosen when reads pass several related leaves) */
+                                 * all candidates of the block (chosen when reads pass several related leaves; any threshold in (0, 1]) */
     uint32_t n_fallback_pairs;  /* pairs the LDS-tile pass could not bin (certified by the fallback kernel) */
     uint64_t n_chunks, tile_entries;
     uint32_t tile_passes_launched, tile_passes_needed;  /* LDS-tile stage: passes over the reused probe buckets */
