@@ -646,11 +646,11 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     size_t guarded = 0;
     for (size_t c = 0; with_guards && c < nl; ++c) guarded += t.guard_off[c + 1] > t.guard_off[c];
     // At thresholds below 1 block mode keeps the k-mer entries: buckets by (block, candidate mask), 8 miss bytes per k-mer.
-    bool block_mode = bucketed && (thr_one || (thr_frac && kn.tile_counts != 0)) && recs_possible && n_tiles_block <= 560 && n_blocks < (1u << 16) * (thr_one ? 256u : 1u) &&
+    bool block_mode = bucketed && (thr_one || (thr_frac && kn.tile_counts != 0)) && recs_possible && n_tiles_block <= 560 && n_blocks < (1u << 16) &&
                       (kn.block >= 0 ? kn.block != 0 : (t.cand_per_read > 1.5 && guarded * 20 <= nl)) && (kn.tile < 0 || kn.tile != 0);
     if (block_mode && !soft_ensure(t.d_T, n_blocks * t.n_words * 64)) block_mode = false;
     if (block_mode && !soft_ensure(t.d_failb, t.d_pairs.n * 8)) block_mode = false;
-    if (block_mode) nc = counts_mode ? n_blocks * 256 : n_blocks;
+    if (block_mode) nc = n_blocks * 256;  // buckets by (block, candidate mask)
     t.last_block_mode = 0;
     uint64_t miss_cap = 0;
     size_t nb = 0;
@@ -785,7 +785,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                                            (counts_mode && !block_mode) ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
                                            (with_guards && !block_mode) ? t.d_owner.p : nullptr,
                                            (with_guards && !block_mode) ? t.d_owner_sorted.p : nullptr,
-                                           block_mode ? (counts_mode ? 2u : 1u) : 0u, 1024, st);
+                                           block_mode ? 2u : 0u, 1024, st);
                 if (with_guards && !block_mode)
                     pfq::launch_bucket_scatter(ga.pairs, ga.cursor, ga.cap, off, cur, sub_log2, t.d_sorted.p,
                                                recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, offw, curw,
@@ -825,7 +825,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 // (thresholds < 1: entries name k-mers, tiles are half the size — pfq::TILE_LOG2_COUNTS)
                 const uint32_t tile_log2 = block_mode ? pfq::TILE_LOG2_BLOCK : (counts_mode ? pfq::TILE_LOG2_COUNTS : pfq::TILE_LOG2);
                 const uint32_t n_tiles = (uint32_t)((t.n_words * 64 + (1ull << tile_log2) - 1) >> tile_log2);
-                const uint32_t chunk_log2 = (block_mode && !counts_mode) ? pfq::CHUNK_PAIRS_LOG2_BLOCK : pfq::CHUNK_PAIRS_LOG2;
+                const uint32_t chunk_log2 = pfq::CHUNK_PAIRS_LOG2;
                 // Thresholds < 1: the tile passes leave the k-mers that are not contained in per-chunk miss bitmaps; k_verify_rec
                 // only sees what could not be binned.  (PFQ_TILE_COUNTS=0: record kernel only.)  Results do not depend on the choice.
                 bool tile_counts = true;
@@ -876,7 +876,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         ta.col_row = t.d_col_row.p;
                         ta.bucket_off = off;
                         ta.sub_log2 = sub_log2;
-                        ta.n_leaves = (uint32_t)((block_mode && counts_mode) ? n_blocks : nc);  // (columns of the passes: blocks, whatever the buckets)
+                        ta.n_leaves = (uint32_t)(block_mode ? n_blocks : nc);  // (columns of the passes: blocks, whatever the buckets)
                         ta.n_tiles = n_tiles;
                         ta.chunks = t.d_chunks.p;
                         ta.max_chunks = (uint32_t)max_chunks;
@@ -979,7 +979,8 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                         pfq::launch_block_count(cf, off + nb, t.d_failb.p, st);
                     }
                     pfq::launch_block_fallback(a, t.d_sorted.p, off + nb, t.d_fail.p, t.d_failb.p, t.d_pair_chunk.p,
-                                               t.last_tile_mode ? t.d_chunks.p : nullptr, v.launched_passes, st);
+                                               t.last_tile_mode ? t.d_chunks.p : nullptr, v.launched_passes,
+                                               t.last_tile_mode ? v.n_flagged : nullptr, t.last_tile_mode ? v.flag_list : nullptr, v.flag_cap, st);
                     // ancestors that are not provably supersets must pass too (query.rs:119-141): the guards of every candidate
                     // that is still standing
                     if (with_guards) pfq::launch_block_guards(a, t.d_sorted.p, off + nb, t.d_failb.p, st);

@@ -151,16 +151,14 @@ constexpr uint32_t MAX_TILES = 1024;               // tiles per filter the passe
 constexpr uint32_t TILE_LOG2_COUNTS = 19;          // 64 KiB tiles (twice the tiles, 128-entry deeper bins than needed)
 constexpr uint32_t ROUND_KMERS_LOG2 = 11;          // flattened k-mers per round of k_tile_bin (= 2 windows x 16 waves)
 constexpr uint32_t MAX_ROUNDS = 256;               // rounds per chunk the tags can name; later pairs take the fallback
-// Reads that pass several related leaves (a phage database is full of strains): BLOCK MODE (threshold 1, trees without guard
-// columns).  A pair is (read, block of 8 consecutive leaf columns, mask of the candidate leaves in it); the block's "filter"
-// is a byte per Bloom bit index — bit j = that bit of leaf 8b + j — so ONE entry tests a probe for all candidate leaves of
-// the block: a read that passes 8 strains costs the probes of one pair instead of eight.  Entry = [mask:8][pair of the
-// chunk:7][byte offset in a 128 KiB tile:17]; chunks of <= 128 pairs.
-// At thresholds below 1 block mode keeps the k-mer entries [round tag:2][k-mer:11][byte offset:17] — no room for a mask, so
-// the buckets are keyed by (block, candidate mask): all pairs of a chunk share their mask, which travels in the chunk's
-// descriptor.  The miss array holds 8 bytes per k-mer, one per leaf of the block.
+// Reads that pass several related leaves (a phage database is full of strains): BLOCK MODE.  A pair is (read, block of 8
+// consecutive leaf columns, mask of the candidate leaves in it); the block's "filter" is a byte per Bloom bit index — bit j =
+// that bit of leaf 8b + j — so ONE entry tests a probe for all candidate leaves of the block: a read that passes 8 strains
+// costs the probes of one pair instead of eight.  The pairs are bucketed by (block, candidate mask): all pairs of a chunk
+// share their mask, which travels in the chunk's descriptor, and the entries stay [pair of the chunk:10][byte offset in a
+// 128 KiB tile:17] (threshold 1) or [round tag:2][k-mer:11][byte offset:17] (thresholds below 1: the miss array then holds
+// 8 bytes per k-mer, one per leaf of the block).  The columns of the passes are the blocks, whatever the buckets.
 constexpr uint32_t TILE_LOG2_BLOCK = 17;           // 2^17 bit indices x 8 leaves = 128 KiB
-constexpr uint32_t CHUNK_PAIRS_LOG2_BLOCK = 7;
 constexpr uint32_t BLOCK_LEAVES_LOG2 = 3;
 struct ChunkDesc {
     uint32_t row;      // filter row of the leaf (block mode: the block)
@@ -206,7 +204,7 @@ struct TileArgs {
     // block mode (see TILE_LOG2_BLOCK)
     uint32_t blocks;             // 1: pairs are (read, block | mask << 24), meta.w likewise; bits = block tables, n_words = bytes / 8 of one
                                  // (with `counts`: buckets = (block << 8) | mask, n_leaves = blocks: a column of the passes is a block)
-    uint32_t chunk_log2;         // pairs per chunk (CHUNK_PAIRS_LOG2, or CHUNK_PAIRS_LOG2_BLOCK)
+    uint32_t chunk_log2;         // pairs per chunk (CHUNK_PAIRS_LOG2)
     uint8_t *failb;              // block mode: [sorted pair][8] a probed bit of that candidate leaf was 0
     // thresholds < 1 (entries name k-mers, see TILE_LOG2_COUNTS)
     float threshold;             // (which prefix of a read's k-mers is binned depends on it)
@@ -239,8 +237,10 @@ void launch_bucket_scatter(const uint2 *pairs, const unsigned long long *n_pairs
 void launch_block_tables(const uint64_t *bits, uint64_t n_words, const uint32_t *d_col_row, uint32_t n_leaves, uint8_t *T, hipStream_t st);
 // block mode: flagged pairs (fail bit 1) certified leaf by leaf against the sliced matrix; then the counts / hits of all pairs
 // (chunks == nullptr: no tile passes ran, every pair is certified here)
+// (n_flagged / flag_list: the compact list of the flagged pairs, when the tile passes ran)
 void launch_block_fallback(const QueryArgs &a, const uint2 *sorted, const uint32_t *n_pairs_ptr, const uint32_t *fail, uint8_t *failb,
-                           const uint32_t *pair_chunk, const ChunkDesc *chunks, uint32_t launched_passes, hipStream_t st);
+                           const uint32_t *pair_chunk, const ChunkDesc *chunks, uint32_t launched_passes, const unsigned int *n_flagged,
+                           const uint32_t *flag_list, uint32_t flag_cap, hipStream_t st);
 // block mode with k-mer entries: turns the miss bytes of the binned pairs into failure bytes (FinalizeArgs: fail, kmiss, kall,
 // pair_kpos, pair_chunk, chunks, launched_passes, sorted, off, hp, threshold)
 void launch_block_count(const FinalizeArgs &a, const uint32_t *n_pairs_ptr, uint8_t *failb, hipStream_t st);

@@ -609,9 +609,9 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
                 }
                 if (pair_used < PAIR_CHUNK) {
                     if (lane == 0) {
-                        // (block mode at thresholds < 1: buckets by (block, mask) — the pairs of a chunk share their mask)
+                        // (block mode: buckets by (block, mask) — the pairs of a chunk share their mask)
                         const uint32_t blk = col >> BLOCK_LEAVES_LOG2;
-                        const uint32_t key = BLOCKS ? (COUNTS ? ((blk << 8) | mask8) : blk) : col;
+                        const uint32_t key = BLOCKS ? ((blk << 8) | mask8) : col;
                         const uint32_t bkt = (key << a.sub_log2) | ((uint32_t)r & ((1u << a.sub_log2) - 1u));
                         a.pairs[pair_base + pair_used] = make_uint2((uint32_t)r, BLOCKS ? (blk | (mask8 << 24)) : col);
                         atomicAdd(&a.bucket_cnt[bkt], 1u);
@@ -1280,7 +1280,7 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
     __shared__ unsigned long long s_sum;
     __shared__ uint32_t s_chunk0, s_w[4];
     const uint32_t c = blockIdx.x, cl = a.chunk_log2;
-    const uint32_t n_sub = (a.blocks && a.counts) ? 256u : 1u;  // buckets of this column
+    const uint32_t n_sub = a.blocks ? 256u : 1u;  // buckets of this column
     // chunks of the column = sum over its buckets
     uint32_t mine = 0;
     if (threadIdx.x < n_sub) {
@@ -1319,7 +1319,8 @@ __global__ void __launch_bounds__(256) k_tile_plan(TileArgs a) {
                 // mean probes per tile + 8 standard deviations of a Poisson count + slack (anything beyond falls back) + the
                 // padding of k_tile_bin's runs (up to 3 entries per round: a round brings >= 96 probes per tile, or 32 pairs)
                 unsigned long long mean = (s_sum * a.hp.num_hashes + a.n_tiles - 1) / a.n_tiles;
-                const unsigned long long dev = (unsigned long long)(8.0f * sqrtf((float)mean)) + 64;
+                // (block mode, small buckets: correlated reads, see k_tile_bin — three times the deviation)
+                const unsigned long long dev = (unsigned long long)(((a.blocks && n < 512u) ? 24.0f : 8.0f) * sqrtf((float)mean)) + 64;
                 uint32_t cap = (uint32_t)((mean + dev + (mean >> 5) + 3 * ((n + 31) / 32 + 2) + 31) & ~31ull);
                 unsigned long long need = (unsigned long long)cap * a.n_tiles;
                 // (where the chunk's buckets go — pass and position in the reused buffer — is decided by k_tile_assign)
@@ -1462,7 +1463,8 @@ __device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, in
     return ((unsigned long long)bcast_u32((uint32_t)(v >> 32), src) << 32) | bcast_u32((uint32_t)v, src);
 }
 // MODE 0: (pair, offset) entries, 128 KiB tiles.  MODE 1 (thresholds < 1): k-mer entries.  MODE 2 (block mode): entries
-// [candidate mask:8][pair:7][byte offset:17] against the byte-per-index table of a block of 8 leaves.
+// [pair:10][byte offset:17] against the byte-per-index table of a block of 8 leaves (the candidate mask comes with the chunk).
+// MODE 3 (block mode at thresholds < 1): k-mer entries against that table.
 template <uint32_t BIN_WAVES, uint32_t BIN_CAP, uint32_t MODE>
 __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
     constexpr bool COUNTS = MODE == 1 || MODE == 3, BLK = MODE == 2;  // (MODE 3: k-mer entries against block tables, no prefix)
@@ -1503,12 +1505,15 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
         }
         if (dsc.pass != a.pass) continue;  // binned in another pass
         uint32_t *bucket0 = a.entries + dsc.base;
+        // (block mode: the pairs of a small bucket — a rare candidate mask — are reads that start next to the same few
+        // mutation sites and share most of their k-mers, so their probes come in multiples: a quarter of the k-mer budget keeps
+        // the 60-entry bins from overflowing; families of 8: 6000 flagged pairs per step without it)
+        const uint32_t KBc = (BLK && dsc.n < 512u && KB > 3u) ? KB / 4u : KB;
         // A round = pairs [p, p + P) of the chunk, K flattened k-mers (what is left of pair p after `koff`, then whole pairs).
         // Lanes 0..31 of every wave hold the candidates p + lane (every wave computes the same); `incl` = inclusive prefix
         // sums of their k-mer counts, qb = record index of flattened k-mer 0 of the lane's pair.
         struct Round {
             uint32_t p, P, K, incl, start;  // start: flattened index of the first k-mer of the lane's pair
-            uint32_t mask;                   // BLK: candidate mask of the lane's pair, in place (bits 24..31)
             unsigned long long koff, qb;
             bool partial;
         };
@@ -1520,7 +1525,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
             // (k-mer entries: only the prefix of the read's k-mers that decides nearly every pair, see prefix_kmers)
             const uint32_t n_all = cand ? m.z - k + 1u : 0u, n_bin = (MODE == 1 && cand) ? prefix_kmers(a.threshold, n_all, k) : n_all;
             const unsigned long long n64 = cand ? (unsigned long long)n_bin - (lane == 0 ? koff : 0ull) : 0ull;
-            const uint32_t n_l = (uint32_t)(n64 > KB ? KB + 1u : n64);  // (more than the budget is all the same)
+            const uint32_t n_l = (uint32_t)(n64 > KBc ? KBc + 1u : n64);  // (more than the budget is all the same)
             uint32_t incl = n_l;
             for (uint32_t sft = 1; sft < ROUND_PAIRS; sft <<= 1) {
                 const uint32_t o = (uint32_t)__shfl_up((int)incl, (int)sft);
@@ -1528,12 +1533,11 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
             }
             r.incl = incl;
             r.start = incl - n_l;
-            r.mask = m.w & 0xff000000u;
-            r.P = (uint32_t)__popcll(ballot64(cand && incl <= KB));  // incl is monotone: a prefix of the candidates
-            r.partial = r.P == 0 && p < dsc.n;  // the first pair alone exceeds the budget: the next KB k-mers of it
+            r.P = (uint32_t)__popcll(ballot64(cand && incl <= KBc));  // incl is monotone: a prefix of the candidates
+            r.partial = r.P == 0 && p < dsc.n;  // the first pair alone exceeds the budget: the next KBc k-mers of it
             if (r.partial) {
                 r.P = 1;
-                r.K = KB;
+                r.K = KBc;
             } else r.K = r.P ? bcast_u32(incl, (int)r.P - 1) : 0u;
             r.qb = (((unsigned long long)m.y << 32) | m.x) + (lane == 0 ? koff : 0ull) - (unsigned long long)(incl - n_l);
             return r;
@@ -1552,20 +1556,17 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                 if (j0 >= r.P) j0 = r.P ? r.P - 1 : 0;  // (window past the end: no valid lane)
                 uint32_t j = j0;
                 unsigned long long qb = bcast_u64(r.qb, (int)j0);
-                uint32_t mk = BLK ? bcast_u32(r.mask, (int)j0) : 0u;
                 for (uint32_t t = j0; t + 1 < r.P; ++t) {
                     const uint32_t e = bcast_u32(r.incl, (int)t);
                     if (e > f0 + 63u) break;
                     const unsigned long long qn = bcast_u64(r.qb, (int)t + 1);
-                    const uint32_t mn = BLK ? bcast_u32(r.mask, (int)t + 1) : 0u;
                     if (f >= e) {
                         j = t + 1;
                         qb = qn;
-                        mk = mn;
                     }
                 }
                 rec[u] = valid[u] ? a.recs[qb + f] : make_uint4(0, 0, 0, 0);  // (no k-mer: every index 0, see `put`)
-                local[u] = ((COUNTS ? f : r.p + j) << TL) | mk;
+                local[u] = (COUNTS ? f : r.p + j) << TL;
             }
         };
         // Software pipeline over the rounds: while round r is binned, the records of round r + 1 and the pair metadata of
@@ -1593,7 +1594,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                 if (wave == 0 && lane < cur.P && (lane > 0 || cur.koff == 0)) a.pair_kpos[dsc.first + cur.p + lane] = k0 + (cur.partial ? 0u : cur.start);
             }
             const uint32_t p1 = cur.partial ? cur.p : cur.p + cur.P;
-            const Round nxt = compose(p1, cur.partial ? cur.koff + KB : 0ull, m_nxt);
+            const Round nxt = compose(p1, cur.partial ? cur.koff + KBc : 0ull, m_nxt);
             uint4 rec_n[WPI];
             uint32_t local_n[WPI];
             bool valid_n[WPI];
@@ -1619,6 +1620,11 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
 #pragma unroll
                     for (uint32_t u = 0; u < WPI; ++u)
                         if (valid[u]) bins[tile[u] * BIN_STRIDE + min(slot[u], BIN_CAP - 1u)] = local[u] | (ix[u] & ((1u << TL) - 1u));
+                    if (BLK) {  // (block mode: exactly the pairs whose probe found its bin full take the fallback — each costs 8 x 1300 line gathers there)
+#pragma unroll
+                        for (uint32_t u = 0; u < WPI; ++u)
+                            if (valid[u] && slot[u] >= BIN_CAP && !(a.debug & 8u)) flag_fallback(a, dsc.first + (local[u] >> TL));
+                    }
                 };
                 uint32_t ix[WPI];
 #pragma unroll
@@ -1662,7 +1668,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                 const uint32_t cn = have ? cnt[t] : 0u, pos = have ? fillp[t] : 0u;
                 const uint32_t cc = cn < BIN_CAP ? cn : BIN_CAP, c4 = (cc + 3u) & ~3u;
                 uint32_t *row = bins + t * BIN_STRIDE;
-                if (sl < c4 - cc) row[cc + sl] = (COUNTS || BLK) ? row[cc - 1u] : ENTRY_PAD;  // (c4 > cc only when cc >= 1; a mask-carrying entry could equal ENTRY_PAD)
+                if (sl < c4 - cc) row[cc + sl] = COUNTS ? row[cc - 1u] : ENTRY_PAD;  // (c4 > cc only when cc >= 1)
                 __builtin_amdgcn_wave_barrier();
                 // what fits is written (k_tile_test reads min(fill, cap) entries: every slot below cap must hold an entry
                 // or padding); the pairs whose probes are dropped — bucket full — take the fallback
@@ -1691,9 +1697,9 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                     for (uint32_t u = 0; u < FB; ++u)
                         if (i0 + u * STEP < wr_eff) *reinterpret_cast<uint4 *>(dst + i0 + u * STEP) = v[u];
                 }
-                if (!COUNTS)
-                    for (uint32_t i = wr + sl; i < cc; i += LPT) flag_fallback(a, dsc.first + ((BLK ? row[i] & 0xffffffu : row[i]) >> TL));
-                if (cn > BIN_CAP || (COUNTS && wr < cc)) {  // the LDS bin (or, with k-mer entries, the bucket) overflowed: whose probes were lost is unknown
+                if (!COUNTS && !(a.debug & 16u))
+                    for (uint32_t i = wr + sl; i < cc; i += LPT) flag_fallback(a, dsc.first + (row[i] >> TL));
+                if (!BLK && (cn > BIN_CAP || (COUNTS && wr < cc))) {  // the LDS bin (or, with k-mer entries, the bucket) overflowed: whose probes were lost is unknown
                     for (uint32_t i = sl; i < flush_P; i += LPT) flag_fallback(a, dsc.first + flush_p + i);
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1772,10 +1778,10 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
     constexpr uint32_t TL = MODE == 1 ? TILE_LOG2_COUNTS : (MODE >= 2 ? TILE_LOG2_BLOCK : TILE_LOG2);
     constexpr uint32_t TILE_BYTES = MODE >= 2 ? (1u << TL) : (1u << (TL - 3));
     constexpr uint32_t TV = TILE_BYTES / 8192u;        // 8-byte loads per thread and tile
-    constexpr uint32_t CL = BLK ? CHUNK_PAIRS_LOG2_BLOCK : CHUNK_PAIRS_LOG2;  // pairs per chunk (LDS bitmap of reported failures)
+    constexpr uint32_t CL = CHUNK_PAIRS_LOG2;  // pairs per chunk (LDS bitmap of reported failures)
     // chunks per unit (block mode: chunks of 128 pairs, a unit should still bring >= 16 k entries; MODE 3: the round tables
     // of 16 chunks are what fits beside the 128 KiB tile)
-    constexpr uint32_t TG = BLK ? 64 : (BLKC ? 16 : TEST_GROUP);
+    constexpr uint32_t TG = (BLK || BLKC) ? 16 : TEST_GROUP;
     constexpr uint32_t RK = COUNTS ? MAX_ROUNDS : 1u;
     extern __shared__ uint32_t s_tile[];  // 2^TL bits
     __shared__ uint32_t s_pref[2][TG + 1], s_first[2][TG], s_misc[2][2], s_kbase[2][TG], s_mask[2][TG];
@@ -1931,7 +1937,7 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
 #pragma unroll
                     for (uint32_t c = 0; c < 4; ++c) {
                         const uint32_t off = ev[c] & ((1u << TL) - 1u);
-                        const uint32_t bad = (ev[c] >> 24) & ~(uint32_t)reinterpret_cast<const uint8_t *>(s_tile)[off];
+                        const uint32_t bad = ev[c] != ENTRY_PAD ? s_mask[buf][cidx[u] >> CL] & ~(uint32_t)reinterpret_cast<const uint8_t *>(s_tile)[off] : 0u;
                         if (bad) {  // candidates whose bit is 0; only what this block has not reported yet goes to memory
                             // (a candidate over a mutation fails hundreds of probes: a plain read sorts out the repeats)
                             const uint32_t lp = (ev[c] >> TL) & ((1u << CL) - 1u), fb = cidx[u] + lp, sh = 8u * (fb & 3u);
@@ -2093,46 +2099,63 @@ void launch_block_tables(const uint64_t *bits, uint64_t n_words, const uint32_t 
 // Block mode: the pairs k_tile_bin could not bin (fail bit 1: a bin or a bucket overflowing, no room for the buckets) are
 // certified here, candidate leaf by candidate leaf, against the sliced matrix (exact, slow: one line gather per probe).
 __global__ void __launch_bounds__(256) k_block_fallback(QueryArgs a, const uint2 *sorted, const uint32_t *n_pairs_ptr, const uint32_t *fail, uint8_t *failb,
-                                                        const uint32_t *pair_chunk, const ChunkDesc *chunks, uint32_t launched_passes) {
+                                                        const uint32_t *pair_chunk, const ChunkDesc *chunks, uint32_t launched_passes,
+                                                        const unsigned int *n_flagged, const uint32_t *flag_list, uint32_t flag_cap) {
     __shared__ BlockLds lds;
     fill_complement(lds.comp);
     __syncthreads();
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, n_pairs = *n_pairs_ptr;
     const uint64_t gw = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave, nw = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    auto certify = [&](uint64_t e, uint32_t r, uint32_t y, uint32_t j) {  // candidate leaf j of pair e = (r, y), by the whole wave
+        const uint64_t o0 = a.off[r], L = a.off[r + 1] - o0;
+        ReadCtx rc;
+        rc.read = a.seq + o0;
+        rc.n = L - a.hp.k + 1;  // deferred reads have k-mers and 1 <= need <= n
+        rc.need = need_kmers(a.threshold, rc.n);
+        rc.maxmiss = rc.n - rc.need;
+        const bool pass = verify_column(lds, wave, a, rc, ((y & 0xffffffu) << BLOCK_LEAVES_LOG2) + j);
+        if (!pass && lane == 0) failb[(e << 3) + j] = 1;
+    };
+    // The flagged pairs come in clusters (the pairs of one round of k_tile_bin are neighbours): from the compact list, a wave
+    // per (pair, candidate leaf), so that a cluster does not wait for one wave.
+    const uint32_t nf = n_flagged ? *n_flagged : 0u;
+    const bool listed = flag_list && nf <= flag_cap;
+    if (listed) {
+        for (uint64_t i = gw; i < (uint64_t)nf * 8u; i += nw) {
+            const uint32_t e = flag_list[i >> 3], j = (uint32_t)(i & 7u);
+            const uint2 p = sorted[e];
+            if ((p.y >> (24 + j)) & 1u) certify(e, p.x, p.y, j);
+        }
+    }
+    // Pairs that were not binned at all: no tile passes (chunks == nullptr), or their chunk's pass was not launched (more than
+    // 256 passes); and the flagged ones when their list overflowed.
     for (uint64_t e0 = gw * 64u; e0 < n_pairs; e0 += nw * 64u) {
         const uint64_t e = e0 + lane;
-        bool flagged = e < n_pairs && (fail[e] & 2u);
-        if (e < n_pairs && !flagged) {  // not binned at all: no tile passes (chunks == nullptr), or its chunk's pass was not launched
-            if (!chunks) flagged = true;
+        bool todo_e = e < n_pairs && (fail[e] & 2u) && !listed;
+        if (e < n_pairs && !(fail[e] & 2u)) {
+            if (!chunks) todo_e = true;
             else {
                 const uint32_t c = pair_chunk[e];
-                flagged = c == 0xffffffffu || chunks[c].pass >= launched_passes;
+                todo_e = c == 0xffffffffu || chunks[c].pass >= launched_passes;
             }
         }
         uint2 p = make_uint2(0, 0);
-        if (flagged) p = sorted[e];
-        uint64_t todo = ballot64(flagged);
+        if (todo_e) p = sorted[e];
+        uint64_t todo = ballot64(todo_e);
         while (todo) {
             const int src = __ffsll((unsigned long long)todo) - 1;
             todo &= todo - 1;
             const uint32_t r = bcast_u32(p.x, src), y = bcast_u32(p.y, src);
-            const uint64_t o0 = a.off[r], L = a.off[r + 1] - o0;
-            ReadCtx rc;
-            rc.read = a.seq + o0;
-            rc.n = L - a.hp.k + 1;  // deferred reads have k-mers and need == n
-            rc.need = need_kmers(a.threshold, rc.n);
-            rc.maxmiss = rc.n - rc.need;
-            for (uint32_t j = 0; j < 8; ++j) {
-                if (!((y >> (24 + j)) & 1u)) continue;
-                const bool pass = verify_column(lds, wave, a, rc, ((y & 0xffffffu) << BLOCK_LEAVES_LOG2) + j);
-                if (!pass && lane == 0) failb[((e0 + (uint32_t)src) << 3) + j] = 1;
-            }
+            for (uint32_t j = 0; j < 8; ++j)
+                if ((y >> (24 + j)) & 1u) certify(e0 + (uint32_t)src, r, y, j);
         }
     }
 }
 void launch_block_fallback(const QueryArgs &a, const uint2 *sorted, const uint32_t *n_pairs_ptr, const uint32_t *fail, uint8_t *failb,
-                           const uint32_t *pair_chunk, const ChunkDesc *chunks, uint32_t launched_passes, hipStream_t st) {
-    hipLaunchKernelGGL(k_block_fallback, dim3(1024), dim3(256), 0, st, a, sorted, n_pairs_ptr, fail, failb, pair_chunk, chunks, launched_passes);
+                           const uint32_t *pair_chunk, const ChunkDesc *chunks, uint32_t launched_passes, const unsigned int *n_flagged,
+                           const uint32_t *flag_list, uint32_t flag_cap, hipStream_t st) {
+    hipLaunchKernelGGL(k_block_fallback, dim3(1024), dim3(256), 0, st, a, sorted, n_pairs_ptr, fail, failb, pair_chunk, chunks, launched_passes,
+                       n_flagged, flag_list, flag_cap);
 }
 
 // Block mode with k-mer entries: the miss bytes of the binned pairs decide their candidates.  A wave per pair, lanes =
@@ -2222,17 +2245,20 @@ void launch_block_guards(const QueryArgs &a, const uint2 *sorted, const uint32_t
 // One block per leaf bucket: pairs that no slice failed are hits (mapped_reads += |pass|, query.rs:143).
 __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
     __shared__ unsigned long long s_cnt, s_bytes;
-    if (a.failb) {  // block mode: bucket = block of 8 leaves; a candidate leaf of a pair hits unless one of its probes failed
-        __shared__ unsigned int s_leaf[8];
-        for (uint32_t c = a.c0 + blockIdx.x; c < a.c1; c += gridDim.x) {
-            if (threadIdx.x < 8) s_leaf[threadIdx.x] = 0;
+    if (a.failb) {  // block mode: a candidate leaf of a pair hits unless one of its failure bytes is set
+        // The pairs are sorted by (block, mask) and nearly all of a block's pairs sit in one bucket: the blocks of this kernel
+        // take slices of 2048 consecutive pairs instead of buckets; a slice spans few blocks of leaves, counted in LDS.
+        __shared__ unsigned int s_leaf[64][8];
+        const uint32_t n_pairs = a.bucket_off[a.c1 << a.sub_log2];
+        for (uint32_t s0 = blockIdx.x * 2048u; s0 < n_pairs; s0 += gridDim.x * 2048u) {
+            for (uint32_t i = threadIdx.x; i < 64 * 8; i += blockDim.x) (&s_leaf[0][0])[i] = 0;
             if (threadIdx.x == 0) s_bytes = 0;
             __syncthreads();
-            unsigned long long bytes = 0;
-            uint32_t blk = 0xffffffffu;  // the block of this bucket's pairs (buckets by block, or by (block, mask))
-            for (uint32_t e = a.bucket_off[c << a.sub_log2] + threadIdx.x; e < a.bucket_off[(c + 1) << a.sub_log2]; e += blockDim.x) {
+            const uint32_t blk0 = a.sorted[s0].y & 0xffffffu, s1 = s0 + 2048u < n_pairs ? s0 + 2048u : n_pairs;
+            unsigned long long bytes = 0, hits = 0;
+            for (uint32_t e = s0 + threadIdx.x; e < s1; e += blockDim.x) {
                 const uint2 p = a.sorted[e];
-                blk = p.y & 0xffffffu;
+                const uint32_t blk = p.y & 0xffffffu;
                 const uint2 fb = *reinterpret_cast<const uint2 *>(a.failb + ((uint64_t)e << 3));
                 uint32_t failed = 0;
 #pragma unroll
@@ -2243,23 +2269,28 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
                 const uint64_t o0 = a.off[p.x], L = a.off[p.x + 1] - o0, n = L - a.hp.k + 1, need = need_kmers(a.threshold, n);
                 for (uint32_t m = (p.y >> 24) & ~failed; m; m &= m - 1u) {
                     const uint32_t j = (uint32_t)__ffs((int)m) - 1u;
-                    atomicAdd(&s_leaf[j], 1u);
+                    if (blk - blk0 < 64u) atomicAdd(&s_leaf[blk - blk0][j], 1u);
+                    else atomicAdd(&a.counts[(blk << BLOCK_LEAVES_LOG2) + j], 1ull);
+                    ++hits;
                     bytes += need * a.hp.num_hashes * 32ull;
                     if (a.hit_pairs) {
                         unsigned long long pos = atomicAdd(a.hit_cursor, 1ull);
-                        if (pos < a.hit_cap) a.hit_pairs[pos] = make_uint2(p.x, ((p.y & 0xffffffu) << BLOCK_LEAVES_LOG2) + j);
+                        if (pos < a.hit_cap) a.hit_pairs[pos] = make_uint2(p.x, (blk << BLOCK_LEAVES_LOG2) + j);
                     }
                 }
             }
-            for (int d = 32; d > 0; d >>= 1) bytes += __shfl_down(bytes, d);
-            if (lane_id() == 0 && bytes) atomicAdd(&s_bytes, bytes);
+            for (int d = 32; d > 0; d >>= 1) {
+                bytes += __shfl_down(bytes, d);
+                hits += __shfl_down(hits, d);
+            }
+            if (lane_id() == 0 && hits) {
+                atomicAdd(&s_bytes, bytes);
+                atomicAdd(&a.stats[ST_HITS], hits);
+            }
             __syncthreads();
-            __shared__ uint32_t s_blk;
-            if (blk != 0xffffffffu) s_blk = blk;  // (every pair of the bucket names the same block)
-            __syncthreads();
-            if (threadIdx.x < 8 && s_leaf[threadIdx.x]) {
-                atomicAdd(&a.counts[(s_blk << BLOCK_LEAVES_LOG2) + threadIdx.x], (unsigned long long)s_leaf[threadIdx.x]);
-                atomicAdd(&a.stats[ST_HITS], (unsigned long long)s_leaf[threadIdx.x]);
+            for (uint32_t i = threadIdx.x; i < 64 * 8; i += blockDim.x) {
+                const unsigned int v = (&s_leaf[0][0])[i];
+                if (v) atomicAdd(&a.counts[((blk0 + (i >> 3)) << BLOCK_LEAVES_LOG2) + (i & 7u)], (unsigned long long)v);
             }
             if (threadIdx.x == 0 && s_bytes) atomicAdd(&a.stats[ST_ALG_BYTES], s_bytes);
             __syncthreads();
@@ -2329,9 +2360,8 @@ __global__ void __launch_bounds__(256) k_finalize(FinalizeArgs a) {
     }
 }
 void launch_finalize(const FinalizeArgs &a, hipStream_t st) {
-    // (block mode with k-mer entries: the buckets that hold nearly all pairs — mask 0xff of every block — are 256 apart:
-    // a grid of 2048 would hand them all to 8 blocks; a block per bucket up to 2^20 of them)
-    uint32_t blocks = a.c1 - a.c0 < (a.failb ? (1u << 20) : 2048u) ? a.c1 - a.c0 : (a.failb ? (1u << 20) : 2048u);
+    uint32_t blocks = a.c1 - a.c0 < 2048u ? a.c1 - a.c0 : 2048u;
+    if (a.failb) blocks = 2048u;  // (block mode: slices of the sorted pairs, not buckets)
     if (a.c1 <= a.c0) return;
     hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, st, a);
 }
