@@ -194,6 +194,13 @@ typedef struct pfq_stats {
     uint32_t n_fallback_pairs;  /* pairs the LDS-tile pass could not bin (certified by the fallback kernel) */
     uint64_t n_chunks, tile_entries;
     uint32_t tile_passes_launched, tile_passes_needed;  /* LDS-tile stage: passes over the reused probe buckets */
+    /* two-level frontier (trees of more than 2048 leaves): the reads are screened against a coarse level of internal
+     * nodes first and every group of leaf columns only sees the reads with a live ancestor there (query.rs:119-141) */
+    uint32_t leaf_groups;       /* groups of leaf columns of the sliced matrix (1 for trees of up to 2048 columns) */
+    uint32_t coarse_cols;       /* columns (internal nodes) of the coarse level this call used; 0: flat frontier */
+    uint32_t coarse_probes;     /* probes per k-mer its screens looked at */
+    uint32_t pad_;
+    uint64_t group_reads;       /* (read, leaf group) combinations the coarse level let through to the leaf level */
 } pfq_stats;
 int pfq_last_stats(pfq_tree *tree, pfq_stats *out);
 /* Force a query path: -1 auto, 0 direct, 1 bucketed. */

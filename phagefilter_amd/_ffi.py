@@ -42,7 +42,8 @@ class Stats(C.Structure):
                 ("n_allhit_reads", C.c_uint64), ("algorithmic_bytes", C.c_uint64), ("path", C.c_uint32),
                 ("n_slices", C.c_uint32), ("tile_mode", C.c_uint32), ("n_fallback_pairs", C.c_uint32),
                 ("n_chunks", C.c_uint64), ("tile_entries", C.c_uint64), ("tile_passes_launched", C.c_uint32),
-                ("tile_passes_needed", C.c_uint32)]
+                ("tile_passes_needed", C.c_uint32), ("leaf_groups", C.c_uint32), ("coarse_cols", C.c_uint32),
+                ("coarse_probes", C.c_uint32), ("pad_", C.c_uint32), ("group_reads", C.c_uint64)]
 
 
 class Profile(C.Structure):

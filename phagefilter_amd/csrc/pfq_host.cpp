@@ -81,6 +81,7 @@ struct Knobs {
     long long record_gb = -1, tile_gb = -1, tile_entries = -1, slice_kb = -1;
     long long verify_blocks = -1, verify_chunk = -1, verify_sub = -1, verify_threads = -1, bin_blocks = -1, test_blocks = -1;
     long long tile = -1, tile_counts = -1, no_tail_batch = -1, bin_narrow = -1, bin_wide = -1, bin_debug = -1, block = -1;
+    long long coarse = -1, coarse_cols = -1, coarse_probes = -1, group_log2 = -1;
 };
 struct KnobName {
     const char *name;
@@ -96,6 +97,8 @@ const KnobName KNOBS[] = {
     {"PFQ_NO_TAIL_BATCH", &Knobs::no_tail_batch}, {"PFQ_BIN_NARROW", &Knobs::bin_narrow},
     {"PFQ_BIN_WIDE", &Knobs::bin_wide},         {"PFQ_BIN_DEBUG", &Knobs::bin_debug},
     {"PFQ_BLOCK", &Knobs::block},
+    {"PFQ_COARSE", &Knobs::coarse},             {"PFQ_COARSE_COLS", &Knobs::coarse_cols},
+    {"PFQ_COARSE_PROBES", &Knobs::coarse_probes}, {"PFQ_GROUP_LOG2", &Knobs::group_log2},
 };
 bool set_knob(Knobs &k, const char *name, const char *value) {
     for (const KnobName &kn : KNOBS)
@@ -153,8 +156,16 @@ struct pfq_tree {
     std::vector<uint32_t> guard_off, guard_col;
     uint32_t rw = 1, rw_log2 = 0, n_cols = 0;
     uint64_t leaf_cap = 0, guard_cap = 0;  // regions of the deferred-pair buffer
-    uint32_t n_groups = 1;           // column groups of the sliced matrix (2048 columns each when there are several)
+    uint32_t n_groups = 1;           // column groups of the sliced matrix (2^group_log2 columns each when there are several)
+    uint32_t group_log2 = 11;
     uint64_t group_stride = 0;       // dwords per group: (n_words * 64 + 1) * rw
+    // two-level frontier (trees of several leaf groups): coarse sliced matrix over an antichain of internal nodes
+    bool coarse_valid = false;
+    uint32_t coarse_cols = 0, coarse_rw = 0, coarse_rw_log2 = 0;
+    double coarse_fill = 0.0;        // mean share of set bits of the coarse columns' filters
+    DevBuf<uint32_t> d_Sc, d_cgrp, d_glists;
+    DevBuf<unsigned int> d_gcur;
+    uint32_t last_coarse_cols = 0, last_coarse_probes = 0, last_leaf_groups = 0;
     DevBuf<uint32_t> d_S, d_col_row, d_guard_off, d_guard_col;
     DevBuf<uint32_t> d_owner, d_owner_sorted, d_gfail;  // trees with guard columns, bucketed path: leaf pair of every pair slot
     DevBuf<unsigned long long> d_counts;
@@ -454,6 +465,143 @@ int reserve_rows(pfq_tree &t, size_t rows) {
     return PFQ_OK;
 }
 
+// An allocation that may fail without failing the call: the caller then takes the next exact path.
+template <typename T>
+bool soft_ensure(DevBuf<T> &b, size_t want) {
+    if (b.ensure(want) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
+// The coarse level of the two-level frontier (pfq::CoarseArgs): an antichain of nodes that covers every leaf, as close to
+// the leaves as `max_cols` columns allow (the node with the most leaves below it is split until the budget is spent), in
+// left-to-right order; column c = the filter of node anti[c] — the filter the reference tests at that node (cache.rs:56-62
+// keys filters by path, so nodes that share a file share the row).  Leaves: t.leaves must be current.
+void pick_antichain(const pfq_tree &t, uint32_t max_cols, std::vector<int32_t> &anti, std::vector<uint32_t> &first, std::vector<uint32_t> &count) {
+    const size_t nn = t.nodes.size();
+    first.assign(nn, 0xffffffffu);
+    count.assign(nn, 0);
+    for (size_t i = 0; i < t.leaves.size(); ++i) {
+        first[t.leaves[i]] = (uint32_t)i;
+        count[t.leaves[i]] = 1;
+    }
+    {   // leaves below every node, first leaf (post-order without recursion)
+        std::vector<std::pair<int32_t, int>> st{{t.root, 0}};
+        while (!st.empty()) {
+            auto &top = st.back();
+            const Node &nd = t.nodes[top.first];
+            if (top.second == 0) {
+                top.second = 1;
+                if (nd.left >= 0) st.push_back({nd.left, 0});
+                continue;
+            }
+            if (top.second == 1) {
+                top.second = 2;
+                if (nd.right >= 0) st.push_back({nd.right, 0});
+                continue;
+            }
+            const int32_t v = top.first;
+            st.pop_back();
+            for (int32_t c : {t.nodes[v].left, t.nodes[v].right})
+                if (c >= 0) {
+                    count[v] += count[c];
+                    first[v] = std::min(first[v], first[c]);
+                }
+        }
+    }
+    auto less = [&](int32_t x, int32_t y) { return count[x] < count[y] || (count[x] == count[y] && x > y); };
+    std::vector<int32_t> heap{t.root};
+    while (true) {
+        const int32_t v = heap.front();
+        const Node &nd = t.nodes[v];
+        if (nd.is_leaf()) break;  // the largest node is a leaf: every node of the antichain is
+        const int kids = (nd.left >= 0) + (nd.right >= 0);
+        if (heap.size() + kids - 1 > max_cols) break;
+        std::pop_heap(heap.begin(), heap.end(), less);
+        heap.pop_back();
+        for (int32_t c : {nd.left, nd.right})
+            if (c >= 0) {
+                heap.push_back(c);
+                std::push_heap(heap.begin(), heap.end(), less);
+            }
+    }
+    std::sort(heap.begin(), heap.end(), [&](int32_t x, int32_t y) { return first[x] < first[y]; });
+    anti.swap(heap);
+}
+
+// Plans the coarse level of the current leaf set: the antichain (1024 columns — one 128-byte line per row — when its filters
+// are empty enough, else 2048) and how full its filters are.  n_cols == 0: no coarse level pays (the screens cannot drop a
+// column whose filter has nearly every bit set); the frontier then runs flat, every leaf group on every read.
+struct CoarsePlan {
+    uint32_t n_cols = 0;
+    std::vector<uint32_t> rows, cgrp;
+    double fill = 0;
+};
+int plan_coarse(pfq_tree &t, CoarsePlan &plan) {
+    plan.n_cols = 0;
+    std::vector<uint32_t> budgets;
+    if (t.knobs.coarse_cols > 0) budgets.push_back((uint32_t)std::min<long long>(2048, std::max<long long>(2, t.knobs.coarse_cols)));
+    else budgets = {1024u, 2048u};
+    for (size_t bi = 0; bi < budgets.size(); ++bi) {
+        std::vector<int32_t> anti;
+        std::vector<uint32_t> first, count;
+        pick_antichain(t, budgets[bi], anti, first, count);
+        const uint32_t C = (uint32_t)anti.size();
+        if (C < 2) return PFQ_OK;
+        std::vector<uint32_t> rows(C), cgrp(C);
+        for (uint32_t c = 0; c < C; ++c) {
+            rows[c] = t.nodes[anti[c]].filter;
+            const uint32_t lo = first[anti[c]] >> t.group_log2, hi = (first[anti[c]] + count[anti[c]] - 1) >> t.group_log2;
+            cgrp[c] = lo | (hi << 16);
+        }
+        DevBuf<uint32_t> d_rows;
+        DevBuf<unsigned long long> d_pop;
+        HIP_TRY(d_rows.ensure(C));
+        HIP_TRY(d_pop.ensure(C));
+        HIP_TRY(hipMemcpy(d_rows.p, rows.data(), C * 4, hipMemcpyHostToDevice));
+        pfq::launch_row_popcount(t.d_bits.p, t.n_words, d_rows.p, C, d_pop.p, nullptr);
+        HIP_TRY(hipGetLastError());
+        std::vector<unsigned long long> pop(C);
+        HIP_TRY(hipMemcpy(pop.data(), d_pop.p, C * 8, hipMemcpyDeviceToHost));
+        double fill = 0;
+        for (unsigned long long v : pop) fill += (double)v / (double)t.nbits;
+        fill /= C;
+        if (fill > 0.62 && bi + 1 < budgets.size()) continue;   // try the finer antichain
+        if (fill > 0.80 && t.knobs.coarse <= 0) return PFQ_OK;  // too full to prune anything (PFQ_COARSE=1: build it anyway)
+        plan.n_cols = C;
+        plan.rows.swap(rows);
+        plan.cgrp.swap(cgrp);
+        plan.fill = fill;
+        return PFQ_OK;
+    }
+    return PFQ_OK;
+}
+int build_coarse(pfq_tree &t, const CoarsePlan &plan) {
+    const uint32_t C = plan.n_cols;
+    uint32_t rwc = 16, rwc_log2 = 4;  // (the dense counting screen takes rows of 16, 32 or 64 words)
+    while (rwc * 32 < C) {
+        rwc <<= 1;
+        ++rwc_log2;
+    }
+    const uint64_t sc_words = ((uint64_t)t.n_words * 64 + 1) * rwc;
+    DevBuf<uint32_t> d_rows;
+    if (!(soft_ensure(t.d_Sc, sc_words) && soft_ensure(t.d_cgrp, C) && soft_ensure(t.d_gcur, pfq::MAX_LEAF_GROUPS) && soft_ensure(d_rows, C)))
+        return PFQ_OK;  // (no room: flat frontier)
+    HIP_TRY(hipMemcpy(d_rows.p, plan.rows.data(), C * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_cgrp.p, plan.cgrp.data(), C * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(t.d_Sc.p, 0, sc_words * 4, nullptr));
+    HIP_TRY(hipMemsetAsync(t.d_Sc.p + sc_words - rwc, 0xff, rwc * 4, nullptr));
+    pfq::launch_transpose(t.d_bits.p, t.n_words, d_rows.p, C, t.d_Sc.p, rwc, sc_words, 11, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    t.coarse_cols = C;
+    t.coarse_rw = rwc;
+    t.coarse_rw_log2 = rwc_log2;
+    t.coarse_fill = plan.fill;
+    t.coarse_valid = true;
+    return PFQ_OK;
+}
+
 int build_layout(pfq_tree &t) {
     if (t.layout_valid) return PFQ_OK;
     PFQ_TRY(finish_topology(t));
@@ -491,15 +639,33 @@ int build_layout(pfq_tree &t) {
     for (uint32_t r : guard_rows) t.col_row.push_back(r);
     t.n_cols = (uint32_t)t.col_row.size();
     uint32_t need_words = std::max<uint32_t>(1, (t.n_cols + 31) / 32);
+    // a wave holds one row of up to 64 dwords (2048 columns) across its lanes; wider trees are cut into column groups,
+    // each with a sliced matrix of its own, and the frontier kernels run once per group — on the reads the coarse level
+    // lists for the group when the tree has one (two-level frontier: groups of 1024 columns, one 128-byte line per row)
+    t.coarse_valid = false;
+    t.coarse_cols = 0;
+    bool want_coarse = nl > 2048 && t.knobs.coarse != 0;
+    t.group_log2 = 11;
+    CoarsePlan plan;
+    if (want_coarse) {
+        t.group_log2 = (t.knobs.group_log2 == 10 || t.knobs.group_log2 == 11) ? (uint32_t)t.knobs.group_log2 : 10u;
+        if (((nl - 1) >> t.group_log2) + 1 > pfq::MAX_LEAF_GROUPS) t.group_log2 = 11;
+        if (((nl - 1) >> t.group_log2) + 1 > pfq::MAX_LEAF_GROUPS) want_coarse = false;  // (flat frontier: every group sees every read)
+        if (want_coarse) PFQ_TRY(plan_coarse(t, plan));
+        if (plan.n_cols == 0) {
+            want_coarse = false;
+            t.group_log2 = 11;
+        }
+    }
+    if (!want_coarse) t.d_Sc.release();
+    const uint32_t group_cols = 1u << t.group_log2;
     t.rw = 4;  // at least 16-byte rows: the dense pre-screen gathers rows with dwordx4 loads
     t.rw_log2 = 2;
-    while (t.rw < need_words && t.rw < 64) {
+    while (t.rw < need_words && t.rw < group_cols / 32) {
         t.rw <<= 1;
         ++t.rw_log2;
     }
-    // a wave holds one row of up to 64 dwords (2048 columns) across its lanes; wider trees are cut into column groups of
-    // 2048, each with a sliced matrix of its own, and the frontier kernels run once per group
-    t.n_groups = std::max<uint32_t>(1, (t.n_cols + 2047) / 2048);
+    t.n_groups = std::max<uint32_t>(1, (t.n_cols + group_cols - 1) / group_cols);
     t.group_stride = ((uint64_t)t.n_words * 64 + 1) * t.rw;  // + the all-ones row of the group
     if (nl == 0) {
         t.layout_valid = true;
@@ -526,9 +692,10 @@ int build_layout(pfq_tree &t) {
     HIP_TRY(hipMemsetAsync(t.d_S.p, 0, s_words * 4, nullptr));
     for (uint32_t g = 0; g < t.n_groups; ++g)
         HIP_TRY(hipMemsetAsync(t.d_S.p + (g + 1) * t.group_stride - t.rw, 0xff, t.rw * 4, nullptr));
-    pfq::launch_transpose(t.d_bits.p, t.n_words, t.d_col_row.p, t.n_cols, t.d_S.p, t.rw, t.group_stride, nullptr);
+    pfq::launch_transpose(t.d_bits.p, t.n_words, t.d_col_row.p, t.n_cols, t.d_S.p, t.rw, t.group_stride, t.group_log2, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
+    if (want_coarse) PFQ_TRY(build_coarse(t, plan));
     t.tables_valid = false;
     t.layout_valid = true;
     return PFQ_OK;
@@ -547,14 +714,6 @@ int ensure_scratch(pfq_tree &t, uint64_t n_reads, bool want_hits) {
     return PFQ_OK;
 }
 constexpr uint64_t CLASSIFY_MAX_BLOCKS = 4096;  // blocks of 4 waves; every wave may leave one reservation partly used
-
-// An allocation that may fail without failing the call: the caller then takes the next exact path.
-template <typename T>
-bool soft_ensure(DevBuf<T> &b, size_t want) {
-    if (b.ensure(want) == hipSuccess) return true;
-    (void)hipGetLastError();
-    return false;
-}
 
 // Scratch of the bucketed path.  false: not enough device memory, the caller stays on the direct kernel.
 bool ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads, bool with_guards) {
@@ -687,6 +846,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             a.threshold = threshold;
             a.S_all = t.d_S.p;
             a.group_stride = t.group_stride;
+            a.group_log2 = t.group_log2;
             a.ones_row = (uint32_t)(t.n_words * 64);
             a.rw = t.rw;
             a.rw_log2 = t.rw_log2;
@@ -707,15 +867,71 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             }
             // the frontier kernels, once per column group that holds leaves (a tree of up to 2048 columns has one group)
             auto classify_groups = [&](bool defer) -> int {
-                const uint32_t leaf_groups = (uint32_t)((nl + 2047) / 2048);
+                const uint32_t group_cols = 1u << t.group_log2;
+                const uint32_t leaf_groups = (uint32_t)((nl + group_cols - 1) / group_cols);
+                // Two-level frontier: the coarse launch screens every read against an antichain of internal nodes and lists
+                // it for the leaf groups below its live columns; a group's launch then sees only its list.
+                // (thresholds < 1: only while the coarse filters are empty enough for <= 4 probes per k-mer to tell a miss)
+                bool two_level = t.coarse_valid && leaf_groups > 1 && (kn.coarse > 0 || !counts_mode || t.coarse_fill <= 0.70);
+                uint32_t list_cap = 0;
+                if (two_level) {
+                    // every read at most once per list + one partly used reservation of 32 per wave of the (two) coarse launches
+                    list_cap = (uint32_t)((n_reads + 2 * 32ull * 4 * (uint64_t)blocks + 63) & ~31ull);
+                    if (!soft_ensure(t.d_glists, (size_t)list_cap * leaf_groups)) two_level = false;
+                }
+                t.last_leaf_groups = leaf_groups;
+                t.last_coarse_cols = t.last_coarse_probes = 0;
+                if (two_level) {
+                    pfq::QueryArgs ac = a;
+                    ac.S = ac.S_all = t.d_Sc.p;
+                    ac.group_stride = 0;
+                    ac.group_log2 = 11;
+                    ac.col0 = 0;
+                    ac.n_leaves = ac.n_cols = t.coarse_cols;
+                    ac.rw = t.coarse_rw;
+                    ac.rw_log2 = t.coarse_rw_log2;
+                    ac.first_group = 1;
+                    pfq::CoarseArgs ca{};
+                    ca.cgrp = t.d_cgrp.p;
+                    ca.n_groups = leaf_groups;
+                    ca.lists = t.d_glists.p;
+                    ca.cursors = t.d_gcur.p;
+                    ca.list_cap = list_cap;
+                    ca.total_leaves = (uint32_t)nl;
+                    // probes per k-mer: enough for a foreign read to lose every coarse column.  Threshold 1 (AND over 4 k-mers):
+                    // columns x fill^(4 p) <= 0.02; below 1: a k-mer must be a miss with probability >= 0.85, 1 - fill^p
+                    const double f = std::min(0.999, std::max(1e-6, t.coarse_fill));
+                    uint32_t np;
+                    if (!counts_mode) {
+                        np = (uint32_t)std::ceil(std::log(0.02 / t.coarse_cols) / (4.0 * std::log(f)));
+                        np = std::min<uint32_t>(std::max<uint32_t>(np, 2), pfq::COARSE_MAX_PROBES);
+                    } else {
+                        np = 1;
+                        while (np < 4 && 1.0 - std::pow(f, (double)np) < 0.85) ++np;
+                        // k-mers looked at beyond maxmiss + 1 + 8, per 256 of maxmiss + 1: what the k-mers that are no misses cost
+                        const double pm = 1.0 - std::pow(f, (double)np);
+                        ca.scr_extra = (uint32_t)std::min(256.0, std::ceil(256.0 * (1.0 / pm - 1.0)));
+                    }
+                    if (kn.coarse_probes > 0) np = (uint32_t)std::min<long long>(kn.coarse_probes, counts_mode ? 4 : pfq::COARSE_MAX_PROBES);
+                    np = std::max<uint32_t>(1, std::min<uint32_t>(np, t.num_hashes));
+                    ca.n_probes = np;
+                    t.last_coarse_cols = t.coarse_cols;
+                    t.last_coarse_probes = np;
+                    HIP_TRY(hipMemsetAsync(t.d_gcur.p, 0, pfq::MAX_LEAF_GROUPS * sizeof(unsigned int), st));
+                    pfq::launch_coarse(ac, ca, counts_mode, blocks, st);
+                }
                 for (uint32_t g = 0; g < leaf_groups; ++g) {
                     a.S = t.d_S.p + (uint64_t)g * t.group_stride;
-                    a.col0 = g * 2048u;
-                    a.n_leaves = (uint32_t)std::min<size_t>(2048, nl - (size_t)g * 2048);
-                    a.first_group = g == 0;
-                    if (g && counts_mode) HIP_TRY(hipMemsetAsync(t.d_cursors.p + 4, 0, 8, st));  // the queue of long reads is per group
+                    a.col0 = g * group_cols;
+                    a.n_leaves = (uint32_t)std::min<size_t>(group_cols, nl - (size_t)g * group_cols);
+                    a.first_group = !two_level && g == 0;
+                    a.read_list = two_level ? t.d_glists.p + (size_t)g * list_cap : nullptr;
+                    a.n_list = two_level ? t.d_gcur.p + g : nullptr;
+                    if ((g || two_level) && counts_mode) HIP_TRY(hipMemsetAsync(t.d_cursors.p + 4, 0, 8, st));  // the queue of long reads is per launch
                     pfq::launch_classify(a, defer, counts_mode, blocks, st);
                 }
+                a.read_list = nullptr;
+                a.n_list = nullptr;
                 return PFQ_OK;
             };
             hipEvent_t *ev = nullptr;
@@ -1994,6 +2210,10 @@ int pfq_last_stats(pfq_tree *tree, pfq_stats *out) {
             out->tile_passes_needed = (uint32_t)std::max<uint64_t>(1, (c[2] + t.hint_entry_cap - 1) / t.hint_entry_cap);
         }
     }
+    out->leaf_groups = t.last_leaf_groups;
+    out->coarse_cols = t.last_coarse_cols;
+    out->coarse_probes = t.last_coarse_probes;
+    out->group_reads = h[pfq::ST_LISTED];
     return PFQ_OK;
 }
 int pfq_profile_begin(pfq_tree *tree, uint32_t max_calls) {
@@ -2041,6 +2261,14 @@ int pfq_profile_end(pfq_tree *tree, pfq_profile *out) {
 int pfq_set_option(pfq_tree *tree, const char *name, const char *value) {
     if (!tree || !name) return fail(PFQ_ERR_ARG, "null argument");
     if (!set_knob(tree->knobs, name, value)) return fail(PFQ_ERR_ARG, std::string("unknown option ") + name);
+    // knobs of the device layout (column groups, coarse level): the layout is rebuilt before the next use
+    if (!strcmp(name, "PFQ_COARSE") || !strcmp(name, "PFQ_COARSE_COLS") || !strcmp(name, "PFQ_GROUP_LOG2")) {
+        if (tree->layout_valid) {
+            PFQ_TRY(use_device(tree->device));
+            PFQ_TRY(sync_counts_to_nodes(*tree));
+            tree->layout_valid = false;
+        }
+    }
     return PFQ_OK;
 }
 int pfq_set_path(pfq_tree *tree, int path) {

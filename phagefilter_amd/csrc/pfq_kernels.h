@@ -16,7 +16,7 @@
 
 namespace pfq {
 
-enum StatSlot { ST_CANDIDATES = 0, ST_HITS = 1, ST_ALLHIT = 2, ST_ALG_BYTES = 3, ST_DEFERRED = 4, ST_N = 8 };
+enum StatSlot { ST_CANDIDATES = 0, ST_HITS = 1, ST_ALLHIT = 2, ST_ALG_BYTES = 3, ST_DEFERRED = 4, ST_LISTED = 5 /* (read, leaf group) entries of a two-level frontier */, ST_N = 8 };
 
 struct QueryArgs {
     HashParams hp;
@@ -29,6 +29,11 @@ struct QueryArgs {
     const uint32_t *S_all;       // group 0 (certificates of arbitrary columns: guards may live in another group)
     uint64_t group_stride;       // dwords between the matrices of consecutive groups
     uint32_t col0;               // first column of this launch's group (columns are global everywhere else)
+    uint32_t group_log2;         // log2 of the columns per group of the sliced matrix (11; 10 for trees with a coarse level)
+    // two-level frontier (trees of several column groups): the launch of a leaf group only sees the reads the coarse launch
+    // (k_coarse) listed for it — reads with a live ancestor of one of the group's leaves
+    const uint32_t *read_list;   // reads of this launch (entries 0xffffffff: unused slots of a reservation), nullptr: all reads
+    const unsigned int *n_list;  // slots of read_list in use
     uint32_t first_group;        // 1: this launch accounts for the per-read statistics (read bytes, all-hit reads)
     uint32_t ones_row;           // index of the all-ones row stored behind the last bit row of S
     uint32_t rw, rw_log2;        // row words (power of two <= 64)
@@ -60,6 +65,28 @@ struct QueryArgs {
     unsigned long long *miss_cursor;   // words reserved so far
     uint64_t miss_cap;                 // words in the buffer
 };
+
+// Two-level frontier (k_coarse).  A tree of more than one column group gets a COARSE sliced matrix over an antichain of
+// internal nodes that covers every leaf (each node as close to the leaves as <= 1024 / 2048 columns allow).  A read that
+// does not pass a node reaches no leaf below it (query.rs:119-141 descends with the survivors only), whatever the
+// threshold and whether or not the node's filter is a superset of its children's; the screens of the leaf groups then run
+// on the reads listed for them instead of on every read.  Filters of internal nodes are fuller than those of leaves, so
+// the coarse screens look at n_probes probes per k-mer instead of one (two at threshold 1).
+constexpr uint32_t MAX_LEAF_GROUPS = 64;   // groups a coarse launch can list reads for (wider trees: flat frontier)
+constexpr uint32_t COARSE_MAX_PROBES = 6;  // probes per k-mer of the coarse AND-screen (threshold 1); the counting screen takes <= 4
+struct CoarseArgs {
+    const uint32_t *cgrp;        // [coarse columns] first leaf group | last leaf group << 16 of the leaves below the column's node
+    uint32_t n_groups;           // leaf groups (<= MAX_LEAF_GROUPS)
+    uint32_t *lists;             // [n_groups][list_cap] reads per leaf group, appended through per-wave reservations of 32
+    unsigned int *cursors;       // [n_groups] slots handed out
+    uint32_t list_cap;           // >= n_reads + 32 per wave of the launch: no list can overflow
+    uint32_t n_probes;           // probes per k-mer the coarse screen looks at
+    uint32_t scr_extra;          // counting screen: k-mers looked at beyond maxmiss + 1
+    uint32_t total_leaves;       // reads that pass every node count at every leaf of the tree
+};
+void launch_coarse(const QueryArgs &a, const CoarseArgs &ca, bool counts_mode, int blocks, hipStream_t st);
+// out[i] = set bits of filter row rows[i]
+void launch_row_popcount(const uint64_t *bits, uint64_t n_words, const uint32_t *d_rows, uint32_t n_rows, unsigned long long *d_out, hipStream_t st);
 
 // Guard pairs (k_expand_guards): second region of the pair buffer, slots slot0 .. slot0 + cap of the whole buffer.
 struct GuardArgs {
@@ -267,7 +294,7 @@ void launch_insert_step(uint64_t *bits, uint64_t n_words, uint32_t cur_row, uint
 void launch_superset(const uint64_t *bits, uint64_t n_words, const uint32_t *d_edges /*(parent,child)*/, uint32_t n_edges,
                      uint32_t *d_fail, hipStream_t st);
 void launch_transpose(const uint64_t *bits, uint64_t n_words, const uint32_t *d_col_row, uint32_t n_cols, uint32_t *S,
-                      uint32_t rw, uint64_t group_stride, hipStream_t st);
+                      uint32_t rw, uint64_t group_stride, uint32_t group_log2, hipStream_t st);
 // dst[i] += src[i] (u64 counters; replicas of one tree on the same device, pfq_trees_allreduce_counts)
 void launch_add_counts(unsigned long long *dst, const unsigned long long *src, uint32_t n, hipStream_t st);
 void launch_debug_indices(const HashParams &hp, const uint8_t *d_seq, uint64_t len, uint64_t *d_out, hipStream_t st);

@@ -28,6 +28,10 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+__device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, int src) {
+    return ((unsigned long long)bcast_u32((uint32_t)(v >> 32), src) << 32) | bcast_u32((uint32_t)v, src);
+}
+
 constexpr uint32_t SCREEN_ROUNDS = 2;  // row loads in flight per lane and probe in the theta=1 screen
 constexpr uint32_t SCREEN_KMERS = 4;   // k-mers the theta=1 screen looks at (rows of narrow trees would allow more per load)
 constexpr uint32_t PAIR_CHUNK = 32;    // slots a wave reserves at a time in the deferred-pair buffer
@@ -46,9 +50,9 @@ struct ReadCtx {
 __device__ __forceinline__ bool verify_column(BlockLds &lds, uint32_t wave, const QueryArgs &a, const ReadCtx &rc,
                                               uint32_t col) {
     const uint32_t lane = lane_id();
-    // `col` is a global column: group col / 2048 of the sliced matrix (a single group holds every column of a narrow tree)
-    const uint32_t *Sg = a.S_all + (uint64_t)(col >> 11) * a.group_stride;
-    const uint32_t cw = (col & 2047u) >> 5, cb = col & 31u;
+    // `col` is a global column: group col >> group_log2 of the sliced matrix (a single group holds every column of a narrow tree)
+    const uint32_t *Sg = a.S_all + (uint64_t)(col >> a.group_log2) * a.group_stride;
+    const uint32_t cw = (col & ((1u << a.group_log2) - 1u)) >> 5, cb = col & 31u;
     uint64_t hits = 0, seen = 0;
     for (uint64_t base = 0; base < rc.n; base += WIN_KMERS) {
         uint32_t cnt = (uint32_t)((rc.n - base) < WIN_KMERS ? (rc.n - base) : WIN_KMERS);
@@ -206,19 +210,30 @@ constexpr uint64_t SHORT_KMERS = 256;
 // Returns the mask of regular reads whose frontier is not empty — their frontier words are left in
 // live_out[j*rw + w], so the per-read path does not gather them again — and in `irregular` the reads it did not
 // screen (no k-mers, need != n).  Reads in neither mask are finished: no leaf can pass them.
+// The group is reads r0 .. r0 + n_in_group - 1, or list[r0 ..] when a list is given (entries 0xffffffff are no reads);
+// `rid` returns the lane's read.  MULTI (the coarse level of a two-level frontier, whose filters are fuller): n_probes
+// probes per k-mer (2 .. COARSE_MAX_PROBES) instead of two.
+template <bool MULTI>
 __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, const uint8_t *comp, uint32_t *live_out,
-                                                 const QueryArgs &a, uint64_t r0, uint32_t n_in_group, uint32_t colmask,
-                                                 uint32_t &irregular, uint64_t &lane_len) {
+                                                 const QueryArgs &a, const uint32_t *list, uint64_t r0, uint32_t n_in_group,
+                                                 uint32_t colmask, uint32_t n_probes, uint32_t &irregular, uint64_t &lane_len,
+                                                 uint32_t &rid) {
     const uint32_t lane = lane_id(), j = lane >> 2, t = lane & 3u, k = a.hp.k;
     const uint32_t rw = a.rw;
     uint64_t o0 = 0, L = 0;
-    if (j < n_in_group) {
-        o0 = a.off[r0 + j];
-        L = a.off[r0 + j + 1] - o0;
+    rid = (uint32_t)(r0 + j);
+    bool present = j < n_in_group;
+    if (list) {
+        rid = present ? list[r0 + j] : 0xffffffffu;
+        present = rid != 0xffffffffu;  // (reads are indexed with 31 bits)
+    }
+    if (present) {
+        o0 = a.off[list ? (uint64_t)rid : r0 + j];
+        L = a.off[(list ? (uint64_t)rid : r0 + j) + 1] - o0;
     }
     lane_len = (t == 0) ? L : 0;  // read length, on the first lane of each read
     const uint64_t n = (L >= k) ? (L - k + 1) : 0;
-    const bool regular = j < n_in_group && n >= 1 && need_kmers(a.threshold, n) == n;
+    const bool regular = present && n >= 1 && need_kmers(a.threshold, n) == n;
     const uint32_t nk = regular ? (uint32_t)(n < DENSE_KMERS ? n : DENSE_KMERS) : 0u;
     const uint32_t W = nk ? nk + k - 1 : 0u;  // bytes of this read that are staged
     uint8_t *fwd = reinterpret_cast<uint8_t *>(fw), *rcb = reinterpret_cast<uint8_t *>(rw_);
@@ -244,8 +259,24 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
     const bool valid = t < nk;
     uint64_t h1, h2;
     kmer_hashes_at(fw, rw_, mb + t, mb + (W - t - k), valid, a.hp, h1, h2);
-    const uint32_t i0v = mod_d(h1, a.hp), i1v = mod_d(h2, a.hp);
+    uint32_t i0v, i1v;
+    uint32_t ixs[MULTI ? COARSE_MAX_PROBES : 1];  // MULTI: probe p of the lane's k-mer
+    if (MULTI) {
+        ProbeIter pit;
+        pit.init(h1, h2, a.hp);
+        ixs[0] = i0v = pit.i0;
+        ixs[1] = i1v = pit.g;
+        ixs[2] = pit.x;
+#pragma unroll
+        for (uint32_t p = 3; p < COARSE_MAX_PROBES; ++p) ixs[p] = p < n_probes ? pit.step(a.hp) : 0u;  // (n_probes <= num_hashes, wave-uniform)
+    } else {
+        i0v = mod_d(h1, a.hp);
+        i1v = mod_d(h2, a.hp);
+    }
     const bool two = a.hp.num_hashes > 1;
+    const uint32_t ppk = MULTI ? n_probes : 2u;                  // rows per k-mer
+    const uint32_t ppk_inv = (65536u + ppk - 1u) / ppk;          // p / ppk == (p * ppk_inv) >> 16 for p < 64
+    const uint64_t present_b = ballot64(present && t == 0);
     uint32_t survive = 0;
     irregular = 0;
     // Row gathers, 16 bytes per lane: a read's 2*nk rows of rw dwords are covered by lanes (row = lane / (rw/4),
@@ -270,13 +301,28 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
             acc[u] = make_uint4(~0u, ~0u, ~0u, ~0u);
             if (jj >= n_in_group) continue;
             const uint32_t nk_j = bcast_u32(nk, (int)((jj < DENSE_READS ? jj : 0u) * 4u));
-            const uint32_t rows = 2u * nk_j;
+            const uint32_t rows = ppk * nk_j;
             for (uint32_t p0 = 0; p0 < rows; p0 += rpi) {
                 const uint32_t p = p0 + rsel;
-                const bool pv = p < rows && ((p & 1u) == 0 || two);
-                const int src = (int)(jj * 4u + ((pv ? p : 0u) >> 1));
-                const uint32_t x0 = (uint32_t)__shfl((int)i0v, src), x1 = (uint32_t)__shfl((int)i1v, src);
-                const uint32_t idx = (p & 1u) ? x1 : x0;
+                uint32_t idx;
+                bool pv;
+                if (MULTI) {
+                    pv = p < rows;
+                    const uint32_t km = ((pv ? p : 0u) * ppk_inv) >> 16, pr = (pv ? p : 0u) - km * ppk;
+                    const int src = (int)(jj * 4u + km);
+                    idx = (uint32_t)__shfl((int)ixs[0], src);
+#pragma unroll
+                    for (uint32_t q = 1; q < COARSE_MAX_PROBES; ++q) {
+                        if (q >= ppk) break;  // (wave-uniform)
+                        const uint32_t xq = (uint32_t)__shfl((int)ixs[q], src);
+                        idx = pr == q ? xq : idx;
+                    }
+                } else {
+                    pv = p < rows && ((p & 1u) == 0 || two);
+                    const int src = (int)(jj * 4u + ((pv ? p : 0u) >> 1));
+                    const uint32_t x0 = (uint32_t)__shfl((int)i0v, src), x1 = (uint32_t)__shfl((int)i1v, src);
+                    idx = (p & 1u) ? x1 : x0;
+                }
                 if (pv) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(a.S + (uint64_t)idx * rw + part * 4u);
                     acc[u].x &= v.x; acc[u].y &= v.y; acc[u].z &= v.z; acc[u].w &= v.w;
@@ -288,8 +334,8 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
             const uint32_t jj = jb + u;
             if (jj >= n_in_group) continue;
             const uint32_t nk_j = bcast_u32(nk, (int)(jj * 4u));
-            if (nk_j == 0) {  // irregular read: leave it to the per-read path
-                irregular |= 1u << jj;
+            if (nk_j == 0) {  // irregular read: leave it to the per-read path (unused slots of a list are no reads)
+                if ((present_b >> (jj * 4u)) & 1ull) irregular |= 1u << jj;
                 continue;
             }
             uint4 l4 = acc[u];
@@ -319,25 +365,35 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
 // 16 in the launch for long reads); other reads are returned in `irregular` for the per-read path.  The group is reads r0 .. r0+n-1, or
 // list[r0 .. r0+n-1] when a list is given; `rid` returns the lane's read.  On return live_out[j*rw + w] holds the
 // frontier words of read j and `survive` the reads with a non-empty frontier.
-template <uint32_t P, uint32_t LPR_LOG2>  // counter planes; log2 of the lanes per read (rw = 4 << LPR_LOG2: 16, 32 or 64)
+// MULTI (the coarse level of a two-level frontier): a k-mer is a definite miss for a column if ANY of its first n_probes
+// probed bits is 0 (1 .. 4; the filters of internal nodes are too full for one bit to tell), and the screen looks at
+// scr_extra k-mers beyond maxmiss + 1 instead of SCREEN_EXTRA.
+template <uint32_t P, uint32_t LPR_LOG2, bool MULTI = false>  // counter planes; log2 of the lanes per read (rw = 4 << LPR_LOG2: 16, 32 or 64)
 __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const uint8_t *comp, uint32_t *live_out,
                                              const QueryArgs &a, const uint32_t *list, uint64_t r0, uint32_t n_in_group,
-                                             uint32_t &survive, uint32_t &irregular, uint64_t &lane_len, uint64_t &rid) {
+                                             uint32_t &survive, uint32_t &irregular, uint64_t &lane_len, uint64_t &rid,
+                                             uint32_t n_probes = 1, uint32_t scr_extra = SCREEN_EXTRA) {
     const uint32_t lane = lane_id(), k = a.hp.k;
     static_assert(LPR_LOG2 >= 2 && LPR_LOG2 <= 4, "rows of 16, 32 or 64 words");
     constexpr uint32_t lpr_log2 = LPR_LOG2, lpr = 1u << lpr_log2, rpw = 64u >> lpr_log2, rw = 4u << lpr_log2;
     const uint32_t j = lane >> lpr_log2, q = lane & (lpr - 1u);
     uint64_t o0 = 0, L = 0;
     rid = 0;
-    if (j < n_in_group) {
+    bool in_group = j < n_in_group;
+    if (in_group) {
         rid = list ? (uint64_t)list[r0 + j] : r0 + j;
+        if (list && (uint32_t)rid == 0xffffffffu) {  // unused slot of a reservation in the list
+            in_group = false;
+            rid = 0;
+        }
+    }
+    if (in_group) {
         o0 = a.off[rid];
         L = a.off[rid + 1] - o0;
     }
     lane_len = (q == 0) ? L : 0;
     const uint64_t n64 = (L >= k) ? (L - k + 1) : 0;
     const uint64_t need = need_kmers(a.threshold, n64);
-    const bool in_group = j < n_in_group;
     // (the counters only have to reach maxmiss + 1: reads of any length whose n - need fits P bits are regular, e.g.
     // 300 bp at theta 0.5 with 8 planes)
     const bool regular = in_group && n64 >= 1 && n64 < (1ull << 31) && need >= 1 && need <= n64 && n64 - need < (1ull << P);
@@ -348,7 +404,7 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
     // (filters that are fuller than a per cent leave lucky leaves alive after that many — 2 % of the leaves survive 65 k-mers
     // at a fill of 7 %, none 81: the limit moves on, a pass at a time, while a leaf of the read is alive but within 2^b misses
     // of dying, 2^b about half of maxmiss; leaves that miss few k-mers — the read's real candidates — do not prolong it)
-    uint32_t n_scr = (maxmiss + 1u + SCREEN_EXTRA + lpr - 1u) & ~(lpr - 1u);  // (whole passes: the lanes are there anyway)
+    uint32_t n_scr = (maxmiss + 1u + (MULTI ? scr_extra : SCREEN_EXTRA) + lpr - 1u) & ~(lpr - 1u);  // (whole passes: the lanes are there anyway)
     if (n_scr > n) n_scr = n;
     irregular = 0;
     {
@@ -421,7 +477,17 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
         kmer_hashes_at(fw, rw_, base + x, base + (W - x - k), valid, a.hp, h1, h2);
         // row indices of the wave go through LDS (live_out is free until the end): a lane fetches the eight of its
         // read with two 16-byte reads; k-mers that do not exist point at the all-ones row behind S (no miss)
-        live_out[lane] = valid ? mod_d(h1, a.hp) : a.ones_row;
+        if (MULTI) {  // probe p of the wave's k-mers at live_out[64 p ..]
+            ProbeIter pit;
+            pit.init(h1, h2, a.hp);
+            live_out[lane] = valid ? pit.i0 : a.ones_row;
+            if (n_probes > 1) live_out[64u + lane] = valid ? pit.g : a.ones_row;
+            if (n_probes > 2) live_out[128u + lane] = valid ? pit.x : a.ones_row;
+            if (n_probes > 3) {
+                const uint32_t x3 = pit.step(a.hp);
+                live_out[192u + lane] = valid ? x3 : a.ones_row;
+            }
+        } else live_out[lane] = valid ? mod_d(h1, a.hp) : a.ones_row;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 1  // (rows of 64 words: two batches of eight gathers; unrolled, the sixteen cost the third wave per SIMD: 33.8 -> 41.4 ms)
         for (uint32_t t0 = 0; t0 < lpr; t0 += 8u) {
@@ -433,6 +499,23 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
             for (uint32_t u = 0; u < 8; ++u) {
                 const uint32_t x = (t0 + u < lpr) ? xs[u] : a.ones_row;  // lpr == 4: the upper four belong to the next read
                 m[u] = *reinterpret_cast<const uint4 *>(a.S + ((uint64_t)x << (lpr_log2 + 2u)) + q * 4u);
+            }
+            if (MULTI) {  // a k-mer is contained only where all its probed bits are set: AND of the probes' rows
+                for (uint32_t pr = 1; pr < n_probes; ++pr) {
+                    const uint4 ya = *reinterpret_cast<const uint4 *>(live_out + 64u * pr + (j << lpr_log2) + t0);
+                    const uint4 yb = *reinterpret_cast<const uint4 *>(live_out + 64u * pr + (j << lpr_log2) + t0 + 4u);
+                    const uint32_t ys[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+                    uint4 mm[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; ++u) {
+                        const uint32_t x = (t0 + u < lpr) ? ys[u] : a.ones_row;
+                        mm[u] = *reinterpret_cast<const uint4 *>(a.S + ((uint64_t)x << (lpr_log2 + 2u)) + q * 4u);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; ++u) {
+                        m[u].x &= mm[u].x; m[u].y &= mm[u].y; m[u].z &= mm[u].z; m[u].w &= mm[u].w;
+                    }
+                }
             }
 #define PFQ_CSA_WORD(F, W_)                                                   \
     {                                                                         \
@@ -520,7 +603,8 @@ __device__ __forceinline__ bool has_batched_tail(uint64_t n) {
 // registers above on its own.  The 64-word build is left alone: bounded, it spills and the harness geometry loses 6 %.)
 // BLOCKS (DEFER, theta == 1, no guard columns): survivors are deferred per block of 8 leaf columns — (read, block | mask of
 // the candidate leaves << 24) — see TILE_LOG2_BLOCK.
-template <bool DEFER, bool COUNTS, bool LONG = false, uint32_t LPR_LOG2 = 0, bool BLOCKS = false>
+// LIST: the launch of a leaf group of a two-level frontier — its reads are the ones k_coarse listed for the group (read_list).
+template <bool DEFER, bool COUNTS, bool LONG = false, uint32_t LPR_LOG2 = 0, bool BLOCKS = false, bool LIST = false>
 __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_LOG2 != 4) ? 3 : 1) k_classify(QueryArgs a) {
     __shared__ BlockLds lds;
     __shared__ DenseLds<(DEFER && !LONG) || COUNTS> dlds;
@@ -664,49 +748,54 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
         }
     };
 
+    // the reads of this launch: all of them, or (leaf group of a two-level frontier) the ones k_coarse listed for the group
+    uint64_t n_work = a.n_reads;
+    if (LIST) n_work = *a.n_list;
+    const uint32_t *const read_list = LIST ? a.read_list : nullptr;
     if (DEFER && !COUNTS && a.rw >= 4u) {
         // groups of DENSE_READS consecutive reads: dense pre-screen, then the per-read path for the survivors
-        const uint64_t n_groups = (a.n_reads + DENSE_READS - 1) / DENSE_READS;
+        const uint64_t n_groups = (n_work + DENSE_READS - 1) / DENSE_READS;
         for (uint64_t g = gw; g < n_groups; g += nw) {
             const uint64_t r0 = g * DENSE_READS;
-            const uint32_t cnt = (uint32_t)(a.n_reads - r0 < DENSE_READS ? a.n_reads - r0 : DENSE_READS);
+            const uint32_t cnt = (uint32_t)(n_work - r0 < DENSE_READS ? n_work - r0 : DENSE_READS);
             uint64_t lane_len;
-            uint32_t irregular;
-            uint32_t survive = dense_screen(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, r0, cnt, colmask,
-                                            irregular, lane_len);
+            uint32_t irregular, rid;
+            uint32_t survive = dense_screen<false>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, read_list, r0, cnt,
+                                                   colmask, 2u, irregular, lane_len, rid);
             if (!(((survive | irregular) >> (lane >> 2)) & 1u)) dense_bytes += lane_len;  // reads finished here still count their bytes
             while (survive) {
                 const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
                 survive &= survive - 1u;
-                process_read(r0 + jj, dlds.live[wave] + jj * rw);
+                process_read(LIST ? (uint64_t)bcast_u32(rid, (int)(jj * 4u)) : r0 + jj, dlds.live[wave] + jj * rw);
             }
             while (irregular) {
                 const uint32_t jj = (uint32_t)__ffs((int)irregular) - 1u;
                 irregular &= irregular - 1u;
-                process_read(r0 + jj, nullptr);
+                process_read(LIST ? (uint64_t)bcast_u32(rid, (int)(jj * 4u)) : r0 + jj, nullptr);
             }
         }
     } else if constexpr (COUNTS && !LONG && LPR_LOG2 >= 2u) {
         // thresholds < 1: groups of 64/(rw/4) consecutive reads through the dense counting screen
-        const uint32_t rpw = 256u >> a.rw_log2;
-        const uint64_t n_groups = (a.n_reads + rpw - 1) / rpw;
+        const uint32_t rpw = 256u >> a.rw_log2, lpr_log2 = a.rw_log2 - 2u;
+        const uint64_t n_groups = (n_work + rpw - 1) / rpw;
         for (uint64_t g = gw; g < n_groups; g += nw) {
             const uint64_t r0 = g * rpw;
-            const uint32_t cnt = (uint32_t)(a.n_reads - r0 < rpw ? a.n_reads - r0 : rpw);
+            const uint32_t cnt = (uint32_t)(n_work - r0 < rpw ? n_work - r0 : rpw);
             uint64_t lane_len, rid;
             uint32_t survive, irregular;
-            dense_counts<8, LPR_LOG2>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, nullptr, r0, cnt, survive,
+            dense_counts<8, LPR_LOG2>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, read_list, r0, cnt, survive,
                                       irregular, lane_len, rid);
-            if (!(((survive | irregular) >> (lane >> (a.rw_log2 - 2u))) & 1u)) dense_bytes += lane_len;
+            if (!(((survive | irregular) >> (lane >> lpr_log2)) & 1u)) dense_bytes += lane_len;
+            const uint32_t rid_lo = (uint32_t)rid;  // reads are indexed with 31 bits (query_device checks)
             while (survive) {
                 const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
                 survive &= survive - 1u;
-                process_read(r0 + jj, dlds.live[wave] + jj * rw);
+                process_read(LIST ? (uint64_t)bcast_u32(rid_lo, (int)(jj << lpr_log2)) : r0 + jj, dlds.live[wave] + jj * rw);
             }
             while (irregular) {
                 const uint32_t jj = (uint32_t)__ffs((int)irregular) - 1u;
                 irregular &= irregular - 1u;
-                process_read(r0 + jj, nullptr);
+                process_read(LIST ? (uint64_t)bcast_u32(rid_lo, (int)(jj << lpr_log2)) : r0 + jj, nullptr);
             }
         }
     } else if constexpr (COUNTS && LONG && LPR_LOG2 >= 2u) {
@@ -736,6 +825,11 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
     } else if (LONG) {
         const uint64_t n_long = *a.n_long;
         for (uint64_t i = gw; i < n_long; i += nw) process_read(a.long_list[i], nullptr);
+    } else if (LIST) {
+        for (uint64_t i = gw; i < n_work; i += nw) {
+            const uint32_t r = read_list[i];
+            if (r != 0xffffffffu) process_read(r, nullptr);
+        }
     } else {
         for (uint64_t r = gw; r < a.n_reads; r += nw) process_read(r, nullptr);
     }
@@ -756,36 +850,192 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
     }
 }
 
-template <bool DEFER, uint32_t LPR_LOG2>
+template <bool DEFER, uint32_t LPR_LOG2, bool LIST>
 static void launch_classify_counts(const QueryArgs &a, dim3 g, dim3 b, hipStream_t st) {
     if (DEFER && a.block_pairs) {
-        hipLaunchKernelGGL((k_classify<DEFER, true, false, LPR_LOG2, DEFER>), g, b, 0, st, a);
+        hipLaunchKernelGGL((k_classify<DEFER, true, false, LPR_LOG2, DEFER, LIST>), g, b, 0, st, a);
         hipLaunchKernelGGL((k_classify<DEFER, true, true, LPR_LOG2, DEFER>), g, b, 0, st, a);
         return;
     }
-    hipLaunchKernelGGL((k_classify<DEFER, true, false, LPR_LOG2>), g, b, 0, st, a);
+    hipLaunchKernelGGL((k_classify<DEFER, true, false, LPR_LOG2, false, LIST>), g, b, 0, st, a);
     hipLaunchKernelGGL((k_classify<DEFER, true, true, LPR_LOG2>), g, b, 0, st, a);  // the reads of >= 256 k-mers it queued
 }
-void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int blocks, hipStream_t st) {
-    dim3 g(blocks), b(256);
+template <bool LIST>
+static void launch_classify_l(const QueryArgs &a, bool defer, bool counts_mode, dim3 g, dim3 b, hipStream_t st) {
     if (!counts_mode) {
-        if (defer && a.block_pairs) hipLaunchKernelGGL((k_classify<true, false, false, 0, true>), g, b, 0, st, a);
-        else if (defer) hipLaunchKernelGGL((k_classify<true, false>), g, b, 0, st, a);
-        else hipLaunchKernelGGL((k_classify<false, false>), g, b, 0, st, a);
+        if (defer && a.block_pairs) hipLaunchKernelGGL((k_classify<true, false, false, 0, true, LIST>), g, b, 0, st, a);
+        else if (defer) hipLaunchKernelGGL((k_classify<true, false, false, 0, false, LIST>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_classify<false, false, false, 0, false, LIST>), g, b, 0, st, a);
         return;
     }
     const uint32_t lp = (a.rw_log2 >= 4u && a.rw_log2 <= 6u) ? a.rw_log2 - 2u : 0u;
     if (defer) {
-        if (lp == 2) launch_classify_counts<true, 2>(a, g, b, st);
-        else if (lp == 3) launch_classify_counts<true, 3>(a, g, b, st);
-        else if (lp == 4) launch_classify_counts<true, 4>(a, g, b, st);
-        else launch_classify_counts<true, 0>(a, g, b, st);
+        if (lp == 2) launch_classify_counts<true, 2, LIST>(a, g, b, st);
+        else if (lp == 3) launch_classify_counts<true, 3, LIST>(a, g, b, st);
+        else if (lp == 4) launch_classify_counts<true, 4, LIST>(a, g, b, st);
+        else launch_classify_counts<true, 0, LIST>(a, g, b, st);
     } else {
-        if (lp == 2) launch_classify_counts<false, 2>(a, g, b, st);
-        else if (lp == 3) launch_classify_counts<false, 3>(a, g, b, st);
-        else if (lp == 4) launch_classify_counts<false, 4>(a, g, b, st);
-        else launch_classify_counts<false, 0>(a, g, b, st);
+        if (lp == 2) launch_classify_counts<false, 2, LIST>(a, g, b, st);
+        else if (lp == 3) launch_classify_counts<false, 3, LIST>(a, g, b, st);
+        else if (lp == 4) launch_classify_counts<false, 4, LIST>(a, g, b, st);
+        else launch_classify_counts<false, 0, LIST>(a, g, b, st);
     }
+}
+void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int blocks, hipStream_t st) {
+    dim3 g(blocks), b(256);
+    if (a.read_list) launch_classify_l<true>(a, defer, counts_mode, g, b, st);
+    else launch_classify_l<false>(a, defer, counts_mode, g, b, st);
+}
+
+// ---- the coarse level of a two-level frontier ----------------------------------------------------------------------------
+// Trees of more than one column group: `a` describes the COARSE sliced matrix (columns = an antichain of internal nodes
+// that covers every leaf, see CoarseArgs).  Every read goes through the dense screens against it — the AND-frontier at
+// threshold 1, the miss-counting frontier below — with n_probes probes per k-mer; a read then joins the list of every
+// leaf group that holds a leaf below one of its live columns, and the launches of the leaf groups (k_classify with
+// read_list) screen, certify or defer exactly those reads.  Exact for any tree: a read that does not pass a node — and the
+// screens only drop a column for bits that are 0 — reaches no leaf below it (query.rs:119-141), superset or not.
+// This launch also does what is per read and not per leaf group: the reads' bytes (statistics), reads that pass every
+// node (need == 0: they count at every leaf of the tree) and reads that pass none (need > n).  Reads the dense screens do
+// not take (no screening possible) are listed for every group.
+template <bool COUNTS, bool LONG, uint32_t LPR_LOG2>
+__global__ void __launch_bounds__(256, 2) k_coarse(QueryArgs a, CoarseArgs ca) {
+    __shared__ uint8_t s_comp[256];
+    __shared__ DenseLds<true> dlds;
+    __shared__ uint32_t s_lbase[WAVES_PER_BLOCK][MAX_LEAF_GROUPS], s_lused[WAVES_PER_BLOCK][MAX_LEAF_GROUPS];
+    fill_complement(s_comp);
+    for (uint32_t i = threadIdx.x; i < WAVES_PER_BLOCK * MAX_LEAF_GROUPS; i += blockDim.x) (&s_lused[0][0])[i] = PAIR_CHUNK;
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t gw = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave, nw = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    const uint32_t rw = a.rw;
+    unsigned long long st_all = 0, st_bytes = 0, dense_bytes = 0, st_listed = 0;
+    const uint64_t all_groups = ca.n_groups >= 64u ? ~0ull : ((1ull << ca.n_groups) - 1ull);
+
+    // read r joins the lists of the leaf groups below its live coarse columns (pre: the frontier words of the read, in LDS;
+    // nullptr: every group)
+    auto emit = [&](uint32_t r, const uint32_t *pre) {
+        uint64_t gset = all_groups;
+        if (pre) {
+            gset = 0;
+            uint32_t w = lane < rw ? pre[lane] : 0u;
+            while (w) {
+                const uint32_t b = (uint32_t)__ffs((int)w) - 1u;
+                w &= w - 1u;
+                const uint32_t rng = ca.cgrp[lane * 32u + b], lo = rng & 0xffffu, hi = rng >> 16;
+                gset |= (hi >= 63u ? ~0ull : ((1ull << (hi + 1u)) - 1ull)) & ~((1ull << lo) - 1ull);
+            }
+            for (int d = 32; d > 0; d >>= 1) gset |= __shfl_xor(gset, d);
+        }
+        gset = bcast_u64(gset, 0);
+        while (gset) {
+            const uint32_t g = (uint32_t)__ffsll((unsigned long long)gset) - 1u;
+            gset &= gset - 1ull;
+            uint32_t used = s_lused[wave][g];
+            if (used == PAIR_CHUNK) {  // (wave-uniform) a new reservation of 32 slots in the group's list
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&ca.cursors[g], PAIR_CHUNK);
+                base = bcast_u32(base, 0);
+                if (lane == 0) s_lbase[wave][g] = base;
+                used = 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                ca.lists[(uint64_t)g * ca.list_cap + s_lbase[wave][g] + used] = r;
+                s_lused[wave][g] = used + 1u;
+            }
+            ++st_listed;
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    // a read the dense screen did not take
+    auto slow = [&](uint32_t r, bool queued_before) {
+        const uint64_t o0 = a.off[r], L = a.off[(uint64_t)r + 1] - o0;
+        const uint64_t n = (L >= a.hp.k) ? (L - a.hp.k + 1) : 0, need = need_kmers(a.threshold, n);
+        if (!queued_before) {
+            if (need == 0) {  // 0 >= 0 at every node: the read reaches and counts at every leaf
+                ++st_all;
+                if (a.allhit_flag && lane == 0) a.allhit_flag[r] = 1;
+                return;
+            }
+            if (need > n) return;  // cannot pass any node
+            if (COUNTS && !LONG && n >= SHORT_KMERS) {  // the second launch screens it with wider counters
+                if (lane == 0) a.long_list[atomicAdd(a.n_long, 1u)] = r;
+                return;
+            }
+        }
+        emit(r, nullptr);
+    };
+    auto finish_group = [&](uint32_t survive, uint32_t irregular, uint32_t rid_lo, uint32_t lanes_log2) {
+        while (survive) {
+            const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
+            survive &= survive - 1u;
+            emit(bcast_u32(rid_lo, (int)(jj << lanes_log2)), dlds.live[wave] + jj * rw);
+        }
+        while (irregular) {
+            const uint32_t jj = (uint32_t)__ffs((int)irregular) - 1u;
+            irregular &= irregular - 1u;
+            slow(bcast_u32(rid_lo, (int)(jj << lanes_log2)), LONG);
+        }
+    };
+    if constexpr (!COUNTS) {
+        uint32_t colmask = 0;  // (unused by the dense screen's survivors; kept for its signature)
+        const uint64_t n_groups = (a.n_reads + DENSE_READS - 1) / DENSE_READS;
+        for (uint64_t g = gw; g < n_groups; g += nw) {
+            const uint64_t r0 = g * DENSE_READS;
+            const uint32_t cnt = (uint32_t)(a.n_reads - r0 < DENSE_READS ? a.n_reads - r0 : DENSE_READS);
+            uint64_t lane_len;
+            uint32_t irregular, rid;
+            const uint32_t survive = dense_screen<true>(dlds.mini[wave][0], dlds.mini[wave][1], s_comp, dlds.live[wave], a, nullptr, r0, cnt,
+                                                        colmask, ca.n_probes, irregular, lane_len, rid);
+            dense_bytes += lane_len;
+            finish_group(survive, irregular, rid, 2u);
+        }
+    } else {
+        constexpr uint32_t lpr_log2 = LPR_LOG2, rpw = 64u >> lpr_log2;
+        const uint64_t n_work = LONG ? (uint64_t)*a.n_long : a.n_reads;
+        const uint64_t n_groups = (n_work + rpw - 1) / rpw;
+        for (uint64_t g = gw; g < n_groups; g += nw) {
+            const uint64_t r0 = g * rpw;
+            const uint32_t cnt = (uint32_t)(n_work - r0 < rpw ? n_work - r0 : rpw);
+            uint64_t lane_len, rid;
+            uint32_t survive, irregular;
+            dense_counts<LONG ? NPLANES : 8, LPR_LOG2, true>(dlds.mini[wave][0], dlds.mini[wave][1], s_comp, dlds.live[wave], a,
+                                                            LONG ? a.long_list : nullptr, r0, cnt, survive, irregular, lane_len, rid,
+                                                            ca.n_probes, ca.scr_extra);
+            if (!LONG) dense_bytes += lane_len;  // (the first launch saw every read)
+            finish_group(survive, irregular, (uint32_t)rid, lpr_log2);
+        }
+    }
+    // unused slots of the last reservations
+    for (uint32_t g = 0; g < ca.n_groups; ++g) {
+        const uint32_t used = s_lused[wave][g];
+        if (used < PAIR_CHUNK && used + lane < PAIR_CHUNK) ca.lists[(uint64_t)g * ca.list_cap + s_lbase[wave][g] + used + lane] = 0xffffffffu;
+    }
+    if (st_all)
+        for (uint32_t c = lane; c < ca.total_leaves; c += 64) atomicAdd(&a.counts[c], st_all);
+    for (int dd = 32; dd > 0; dd >>= 1) dense_bytes += __shfl_down(dense_bytes, dd);
+    st_bytes += bcast_u64(dense_bytes, 0);
+    if (lane == 0) {
+        if (st_all) atomicAdd(&a.stats[ST_ALLHIT], st_all);
+        if (st_bytes) atomicAdd(&a.stats[ST_ALG_BYTES], st_bytes);
+        if (st_listed) atomicAdd(&a.stats[ST_LISTED], st_listed);
+    }
+}
+template <uint32_t LPR_LOG2>
+static void launch_coarse_counts(const QueryArgs &a, const CoarseArgs &ca, dim3 g, dim3 b, hipStream_t st) {
+    hipLaunchKernelGGL((k_coarse<true, false, LPR_LOG2>), g, b, 0, st, a, ca);
+    hipLaunchKernelGGL((k_coarse<true, true, LPR_LOG2>), g, b, 0, st, a, ca);  // the reads of >= 256 k-mers it queued
+}
+void launch_coarse(const QueryArgs &a, const CoarseArgs &ca, bool counts_mode, int blocks, hipStream_t st) {
+    dim3 g(blocks), b(256);
+    if (!counts_mode) {
+        hipLaunchKernelGGL((k_coarse<false, false, 0>), g, b, 0, st, a, ca);
+        return;
+    }
+    // (the host builds coarse matrices with rows of 16, 32 or 64 words)
+    if (a.rw_log2 == 4u) launch_coarse_counts<2>(a, ca, g, b, st);
+    else if (a.rw_log2 == 5u) launch_coarse_counts<3>(a, ca, g, b, st);
+    else launch_coarse_counts<4>(a, ca, g, b, st);
 }
 
 // Guard columns on the bucketed path.  k_classify<DEFER> defers (read, leaf) pairs only; for trees with guard columns
@@ -1458,9 +1708,6 @@ __device__ __forceinline__ void flag_fallback(const TileArgs &a, uint32_t e) {
         const uint32_t pos = atomicAdd(a.n_flagged, 1u);
         if (pos < a.flag_cap) a.flag_list[pos] = e;
     }
-}
-__device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, int src) {
-    return ((unsigned long long)bcast_u32((uint32_t)(v >> 32), src) << 32) | bcast_u32((uint32_t)v, src);
 }
 // MODE 0: (pair, offset) entries, 128 KiB tiles.  MODE 1 (thresholds < 1): k-mer entries.  MODE 2 (block mode): entries
 // [pair:10][byte offset:17] against the byte-per-index table of a block of 8 leaves (the candidate mask comes with the chunk).
@@ -2469,10 +2716,10 @@ void launch_superset(const uint64_t *bits, uint64_t n_words, const uint32_t *d_e
 
 // node-major -> sliced: wave = 64 columns x 4 consecutive u64 words; `__ballot` transposes 64 columns x 1 bit.
 __global__ void __launch_bounds__(256) k_transpose(const uint64_t *bits, uint64_t n_words, const uint32_t *col_row,
-                                                   uint32_t n_cols, uint32_t *S, uint32_t rw, uint64_t group_stride) {
+                                                   uint32_t n_cols, uint32_t *S, uint32_t rw, uint64_t group_stride, uint32_t group_log2) {
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, cg = blockIdx.y;
-    S += (uint64_t)(cg >> 5) * group_stride;  // 32 x 64 columns per group of the sliced matrix
-    const uint32_t cgl = cg & 31u;
+    S += (uint64_t)(cg >> (group_log2 - 6u)) * group_stride;  // 2^(group_log2 - 6) x 64 columns per group of the sliced matrix
+    const uint32_t cgl = cg & ((1u << (group_log2 - 6u)) - 1u);
     const uint32_t col = cg * 64u + lane;
     const bool has = col < n_cols;
     const uint64_t *src = bits + (uint64_t)(has ? col_row[col] : 0u) * n_words;
@@ -2507,12 +2754,27 @@ void launch_add_counts(unsigned long long *dst, const unsigned long long *src, u
     if (n) hipLaunchKernelGGL(k_add_counts, dim3((n + 255) / 256), dim3(256), 0, st, dst, src, n);
 }
 void launch_transpose(const uint64_t *bits, uint64_t n_words, const uint32_t *d_col_row, uint32_t n_cols, uint32_t *S,
-                      uint32_t rw, uint64_t group_stride, hipStream_t st) {
+                      uint32_t rw, uint64_t group_stride, uint32_t group_log2, hipStream_t st) {
     if (!n_cols) return;
     uint32_t groups = (n_cols + 63) / 64;
     uint64_t bx = (n_words + 15) / 16;
     if (bx > 4096) bx = 4096;
-    hipLaunchKernelGGL(k_transpose, dim3((uint32_t)bx, groups), dim3(256), 0, st, bits, n_words, d_col_row, n_cols, S, rw, group_stride);
+    hipLaunchKernelGGL(k_transpose, dim3((uint32_t)bx, groups), dim3(256), 0, st, bits, n_words, d_col_row, n_cols, S, rw, group_stride, group_log2);
+}
+
+// Set bits per filter row (how full the coarse level's filters are decides how many probes its screens look at).
+__global__ void __launch_bounds__(256) k_row_popcount(const uint64_t *bits, uint64_t n_words, const uint32_t *rows, unsigned long long *out) {
+    __shared__ unsigned long long s_w[4];
+    const uint64_t *src = bits + (uint64_t)rows[blockIdx.x] * n_words;
+    unsigned long long c = 0;
+    for (uint64_t i = threadIdx.x; i < n_words; i += blockDim.x) c += (unsigned long long)__popcll(src[i]);
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+void launch_row_popcount(const uint64_t *bits, uint64_t n_words, const uint32_t *d_rows, uint32_t n_rows, unsigned long long *d_out, hipStream_t st) {
+    if (n_rows) hipLaunchKernelGGL(k_row_popcount, dim3(n_rows), dim3(256), 0, st, bits, n_words, d_rows, d_out);
 }
 
 // ---- test / bench helpers ----------------------------------------------------------------------------------------------
