@@ -354,6 +354,8 @@ def main() -> None:
             "query_path": "bucketed(screen + leaf-sorted certificates)" if st.path == 1 else "direct",
             "n_slices": int(st.n_slices), "tile_mode": int(st.tile_mode), "fallback_pairs": int(st.n_fallback_pairs),
             "tile_chunks": int(st.n_chunks), "tile_entries": int(st.tile_entries),
+            "leaf_groups": int(st.leaf_groups), "coarse_cols": int(st.coarse_cols), "coarse_probes": int(st.coarse_probes),
+            "group_reads_last_step": int(st.group_reads),
             "kernel_ms_per_step": {k: v / calls for k, v in kern.items()}, "per_kernel": per_kernel,
             "hits_total": total_hits, "hits_last_step": int(st.n_hits), "candidates_last_step": int(st.n_candidates),
             "setup_seconds": setup_s,

@@ -716,7 +716,7 @@ int ensure_scratch(pfq_tree &t, uint64_t n_reads, bool want_hits) {
 constexpr uint64_t CLASSIFY_MAX_BLOCKS = 4096;  // blocks of 4 waves; every wave may leave one reservation partly used
 
 // Scratch of the bucketed path.  false: not enough device memory, the caller stays on the direct kernel.
-bool ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads, bool with_guards) {
+bool ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads, bool with_guards, uint64_t launch_waves) {
     if (!t.h_pair_cursor) {
         if (hipHostMalloc((void **)&t.h_pair_cursor, 64, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
@@ -736,7 +736,7 @@ bool ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads, bool with_guards) {
     // room for two candidates per read, or for 1.3 x what recent calls deferred (at most 24 per read: 40 B per slot);
     // + one partially used reservation per wave.  Pairs that do not fit are certified inline (exact, slow).
     const double per_read = std::min(24.0, std::max(2.0, 1.3 * t.pairs_per_read));
-    uint64_t cap = ((uint64_t)(per_read * (double)n_reads) + 32 * 4 * CLASSIFY_MAX_BLOCKS + 1024 + 31) & ~31ull;
+    uint64_t cap = ((uint64_t)(per_read * (double)n_reads) + pfq::PAIR_RESERVE * launch_waves + 1024 + 31) & ~31ull;
     // pairs deferred by k_classify: slots [0, leaf_cap); guard pairs (k_expand_guards): [leaf_cap, leaf_cap + guard_cap),
     // sized by the tree's guards per leaf (what does not fit is certified inline there)
     if (t.d_pairs.n && t.leaf_cap >= cap) cap = t.leaf_cap;  // (the buffers only grow)
@@ -791,7 +791,15 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     // probe records: hash survivors once instead of once per slice (needs d < 2^30, <= 35 hashes, room)
     if (bucketed && recs_possible && !soft_ensure(t.d_recs, total_bytes + 64)) recs_possible = false;
     if (bucketed && thr_frac && !recs_possible) bucketed = false;  // the miss bits of thresholds < 1 come from the records
-    if (bucketed && !ensure_bucket_scratch(t, n_reads, with_guards)) bucketed = false;
+    // the classify launches of this call: one per group of leaf columns (two for thresholds < 1: reads of >= 256 k-mers), on
+    // all reads, or — two-level frontier — on the reads the coarse launch lists for the group
+    const uint32_t group_cols = 1u << t.group_log2;
+    const uint32_t leaf_groups = (uint32_t)std::max<size_t>(1, (nl + group_cols - 1) / group_cols);
+    const int blocks = (int)std::min<uint64_t>((n_reads + 3) / 4, CLASSIFY_MAX_BLOCKS);  // (2048: 10.1 ms, 4096: 9.9 ms per step)
+    const bool want_two_level = t.coarse_valid && leaf_groups > 1 && (kn.coarse > 0 || threshold >= 1.0f || t.coarse_fill <= 0.70);
+    const int blocks_group = want_two_level ? std::min(blocks, 1024) : blocks;  // (a list holds a fraction of the reads)
+    const uint64_t launch_waves = 4ull * (uint64_t)blocks_group * leaf_groups * (threshold >= 1.0f ? 1 : 2);
+    if (bucketed && !ensure_bucket_scratch(t, n_reads, with_guards, launch_waves)) bucketed = false;
     if (bucketed && recs_possible && !soft_ensure(t.d_meta, t.d_pairs.n)) recs_possible = false;
     if (bucketed && thr_frac && !recs_possible) bucketed = false;
     const bool counts_mode = !(threshold >= 1.0f);  // theta >= 1: need >= n for every read with k-mers
@@ -821,7 +829,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
         if (block_mode && !soft_ensure(t.d_bucket, 3 * nb + 2)) bucketed = false;  // (buckets by (block, mask) outnumber the columns of small trees)
         if (counts_mode && !block_mode) {  // thresholds < 1: every deferred pair owns ceil(n/64) words of k-mer miss bits that the slices OR into
             const uint64_t avg_len = n_reads ? total_bytes / n_reads : 0;
-            miss_cap = std::min<uint64_t>((t.leaf_cap + t.guard_cap) * ((avg_len >> 6) + 2) + 4 * CLASSIFY_MAX_BLOCKS * 1024ull, 0xfffffff0ull);
+            miss_cap = std::min<uint64_t>((t.leaf_cap + t.guard_cap) * ((avg_len >> 6) + 2) + (launch_waves + 4 * 2048) * (uint64_t)pfq::MISS_RESERVE, 0xfffffff0ull);
             if (!(soft_ensure(t.d_miss_words, miss_cap) && soft_ensure(t.d_miss_pos, t.d_pairs.n) && soft_ensure(t.d_bucket_w, 3 * nb + 2)))
                 bucketed = false;
         }
@@ -859,7 +867,6 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             a.hit_cursor = t.d_cursors.p;
             a.allhit_flag = want_hits ? t.d_allhit.p : nullptr;
             a.stats = t.d_stats.p;
-            int blocks = (int)std::min<uint64_t>((n_reads + 3) / 4, CLASSIFY_MAX_BLOCKS);  // (2048: 10.1 ms, 4096: 9.9 ms per step)
             if (counts_mode) {
                 HIP_TRY(t.d_long.ensure(n_reads + 1));
                 a.long_list = t.d_long.p;
@@ -867,12 +874,10 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             }
             // the frontier kernels, once per column group that holds leaves (a tree of up to 2048 columns has one group)
             auto classify_groups = [&](bool defer) -> int {
-                const uint32_t group_cols = 1u << t.group_log2;
-                const uint32_t leaf_groups = (uint32_t)((nl + group_cols - 1) / group_cols);
                 // Two-level frontier: the coarse launch screens every read against an antichain of internal nodes and lists
                 // it for the leaf groups below its live columns; a group's launch then sees only its list.
                 // (thresholds < 1: only while the coarse filters are empty enough for <= 4 probes per k-mer to tell a miss)
-                bool two_level = t.coarse_valid && leaf_groups > 1 && (kn.coarse > 0 || !counts_mode || t.coarse_fill <= 0.70);
+                bool two_level = want_two_level;
                 uint32_t list_cap = 0;
                 if (two_level) {
                     // every read at most once per list + one partly used reservation of 32 per wave of the (two) coarse launches
@@ -928,7 +933,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                     a.read_list = two_level ? t.d_glists.p + (size_t)g * list_cap : nullptr;
                     a.n_list = two_level ? t.d_gcur.p + g : nullptr;
                     if ((g || two_level) && counts_mode) HIP_TRY(hipMemsetAsync(t.d_cursors.p + 4, 0, 8, st));  // the queue of long reads is per launch
-                    pfq::launch_classify(a, defer, counts_mode, blocks, st);
+                    pfq::launch_classify(a, defer, counts_mode, two_level ? blocks_group : blocks, st);
                 }
                 a.read_list = nullptr;
                 a.n_list = nullptr;

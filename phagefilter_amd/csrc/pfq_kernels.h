@@ -16,6 +16,9 @@
 
 namespace pfq {
 
+// Per-wave reservations in the deferred-pair buffer (slots) and in the miss-word buffer (u64 words): every wave of every
+// classify launch may leave one of each partly used, which the host adds to the buffers' sizes.
+constexpr uint32_t PAIR_RESERVE = 32, MISS_RESERVE = 256;
 enum StatSlot { ST_CANDIDATES = 0, ST_HITS = 1, ST_ALLHIT = 2, ST_ALG_BYTES = 3, ST_DEFERRED = 4, ST_LISTED = 5 /* (read, leaf group) entries of a two-level frontier */, ST_N = 8 };
 
 struct QueryArgs {

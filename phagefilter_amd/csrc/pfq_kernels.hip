@@ -35,6 +35,7 @@ __device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, in
 constexpr uint32_t SCREEN_ROUNDS = 2;  // row loads in flight per lane and probe in the theta=1 screen
 constexpr uint32_t SCREEN_KMERS = 4;   // k-mers the theta=1 screen looks at (rows of narrow trees would allow more per load)
 constexpr uint32_t PAIR_CHUNK = 32;    // slots a wave reserves at a time in the deferred-pair buffer
+static_assert(PAIR_CHUNK == PAIR_RESERVE && 256u == MISS_RESERVE, "the host sizes the buffers' slack by these");
 constexpr uint32_t SCREEN_EXTRA = 8;   // k-mers the theta<1 screens look at beyond the maxmiss + 1 that can empty a frontier
 constexpr uint32_t NPLANES = 16;       // vertical-counter planes of the theta<1 screen (k-mers per read < 65536)
 
@@ -622,7 +623,7 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
     // cursor per chunk (a single hot address saturates at ~88 atomics/us); unused slots are voided at the end
     unsigned long long pair_base = 0;
     uint32_t pair_used = PAIR_CHUNK;
-    uint32_t miss_left = 0;  // thresholds < 1: miss words this wave may still hand out (reserved 1024 at a time)
+    uint32_t miss_left = 0;  // thresholds < 1: miss words this wave may still hand out (reserved MISS_RESERVE at a time)
 
     auto process_read = [&](uint64_t r, const uint32_t *pre) {  // pre: frontier words from the dense counting screen
         const uint64_t o0 = a.off[r], L = a.off[r + 1] - o0;
@@ -675,7 +676,7 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
             // (guard columns — ancestors that are not provably supersets — of a deferred pair: k_expand_guards)
             const uint32_t miss_need = (COUNTS && a.bucket_words) ? (rc.n < (1ull << 37) ? (uint32_t)((rc.n + 63) >> 6) : 0xffffffffu) : 0u;
             if (DEFER && COUNTS && a.bucket_words && miss_left < miss_need && miss_need != 0xffffffffu) {  // wave-uniform
-                const uint32_t want = miss_need > 1024u ? miss_need : 1024u;
+                const uint32_t want = miss_need > MISS_RESERVE ? miss_need : MISS_RESERVE;
                 unsigned long long got = 0;
                 if (lane == 0) got = atomicAdd(a.miss_cursor, (unsigned long long)want);
                 got = ((unsigned long long)bcast_u32((uint32_t)(got >> 32), 0) << 32) | bcast_u32((uint32_t)got, 0);
@@ -1080,7 +1081,7 @@ __global__ void __launch_bounds__(256) k_expand_guards(QueryArgs a, GuardArgs ga
                 const uint32_t cnt = n_guard - gg < PAIR_CHUNK ? n_guard - gg : PAIR_CHUNK;
                 const uint32_t miss_need = miss_one * cnt;
                 if (a.bucket_words && miss_left < miss_need) {
-                    const uint32_t want = miss_need > 1024u ? miss_need : 1024u;
+                    const uint32_t want = miss_need > MISS_RESERVE ? miss_need : MISS_RESERVE;
                     unsigned long long got = 0;
                     if (lane == 0) got = atomicAdd(a.miss_cursor, (unsigned long long)want);
                     got = ((unsigned long long)bcast_u32((uint32_t)(got >> 32), 0) << 32) | bcast_u32((uint32_t)got, 0);
