@@ -158,6 +158,13 @@ int pfq_save_leaf_counts(pfq_tree *tree, const char *csv_path);
 int pfq_leaf_counts_export(pfq_tree *tree, uint64_t *d_dst, void *stream);
 int pfq_leaf_counts_import(pfq_tree *tree, const uint64_t *d_src, void *stream);
 int pfq_leaf_counts_reset(pfq_tree *tree);
+/* The same hooks for what THIS replica counted: export_delta writes counters - base, where the base is what the counters held
+ * when the tree was opened (BloomNode::mapped_reads stored in tree.bin — non-zero in a database that was saved after a query),
+ * last reset, imported or reduced; import_delta(sum of the ranks' deltas) sets counters = base + sum and makes that the new
+ * base.  Reducing deltas keeps stored counts from being added once per rank: every rank ends with stored + new, like one
+ * device and like the reference (query.rs:143 accumulates on the loaded value).  pfq_leaf_counts_import also sets the base. */
+int pfq_leaf_counts_export_delta(pfq_tree *tree, uint64_t *d_dst, void *stream);
+int pfq_leaf_counts_import_delta(pfq_tree *tree, const uint64_t *d_src, void *stream);
 
 /* Number of HIP devices this process can use (`--devices all` of the CLI). */
 int pfq_device_count(int *n);
@@ -165,9 +172,11 @@ int pfq_device_count(int *n);
 /* Several GPUs behind one process (the block loop of main.rs:334-368 dealt over devices): `trees` are replicas of one
  * database (pfq_tree_open of the same directory, same pruning) on any devices, each fed its own share of the reads by its
  * own host thread.  This sums their per-leaf counters so that afterwards EVERY replica holds the job's totals
- * (mapped_reads of query.rs:143 as if one tree had seen all reads): replicas that share a device are added on that device,
- * then ONE ncclAllReduce(sum, uint64, n_leaves) over RCCL / xGMI runs across the distinct devices (8 KiB at 1024 leaves).
- * Waits for the replicas' queued work.  librccl is loaded when this first meets replicas on more than one device
+ * (mapped_reads of query.rs:143 as if one tree had seen all reads): what each replica counted since it was opened (or last
+ * reduced) is added — replicas that share a device on that device, then ONE ncclAllReduce(sum, uint64, n_leaves) over RCCL /
+ * xGMI across the distinct devices (8 KiB at 1024 leaves) — onto the counts the database was opened with, which therefore
+ * count once; calling it again without new queries changes nothing.  The communicator of a device set is created on first
+ * use and kept until the last tree of the process is closed.  Waits for the replicas' queued work.  librccl is loaded when this first meets replicas on more than one device
  * (PFQ_RCCL_ALWAYS=1: a one-rank communicator even then, for exercising the path on a one-GPU box). */
 int pfq_trees_allreduce_counts(pfq_tree *const *trees, uint32_t n_trees);
 /* Number of RCCL ranks the last pfq_trees_allreduce_counts on this thread used (0: no communicator was needed). */

@@ -14,6 +14,7 @@ SYMBOLS = [
     "pfq_tree_build_balanced_subtree_device", "pfq_trees_allreduce_counts", "pfq_last_allreduce_ranks", "pfq_device_count", "pfq_set_option", "pfq_tree_save", "pfq_tree_info",
     "pfq_tree_prune", "pfq_tree_close", "pfq_query_batch", "pfq_query_batch_device", "pfq_leaf_counts",
     "pfq_save_leaf_counts", "pfq_leaf_counts_export", "pfq_leaf_counts_import", "pfq_leaf_counts_reset",
+    "pfq_leaf_counts_export_delta", "pfq_leaf_counts_import_delta",
     "pfq_last_stats", "pfq_set_path", "pfq_profile_begin", "pfq_profile_end", "pfq_debug_kmer_indices", "pfq_debug_node_filter", "pfq_synth_genomes_device",
     "pfq_synth_reads_device", "pfq_host_alloc", "pfq_host_free", "pfq_last_error", "pfq_version",
 ]
@@ -95,6 +96,8 @@ def lib() -> C.CDLL:
     L.pfq_save_leaf_counts.argtypes = [vp, C.c_char_p]
     L.pfq_leaf_counts_export.argtypes = [vp, vp, vp]
     L.pfq_leaf_counts_import.argtypes = [vp, vp, vp]
+    L.pfq_leaf_counts_export_delta.argtypes = [vp, vp, vp]
+    L.pfq_leaf_counts_import_delta.argtypes = [vp, vp, vp]
     L.pfq_leaf_counts_reset.argtypes = [vp]
     L.pfq_last_stats.argtypes = [vp, C.POINTER(Stats)]
     L.pfq_set_path.argtypes = [vp, C.c_int]

@@ -921,7 +921,14 @@ int cmd_query(int argc, char **argv) {
 
     const uint64_t t_loop0 = ReadQueue::now_ns();
     std::atomic<uint64_t> ns_gpu{0}, ns_out{0}, n_total{0};
-    auto fail_from_thread = [](const char *what) { die(std::string("libpfq: ") + what); };
+    // An error on a worker thread ends the process at once, WITHOUT exit(): exit() would run the atexit handlers and static
+    // destructors (the HIP runtime's among them) while the other replicas' threads, the parser and the formatters are still
+    // inside HIP calls or writing.  Same message and status as die() (the reference panics: status 101).
+    auto fail_from_thread = [](const char *what) {
+        fprintf(stderr, "phage_filter: libpfq: %s\n", what);
+        fflush(stderr);
+        _exit(101);
+    };
     if (block == 0) {
         // nothing to do: see above
     } else if (!filtering) {

@@ -50,6 +50,7 @@ struct Node {
     bool has_tax = false;
     std::string tax_id;
     uint64_t mapped_reads = 0;
+    uint64_t base_reads = 0;  // mapped_reads as stored / last reset, imported or reduced (see pfq_tree::d_counts_base)
     uint32_t filter = 0;  // row of d_bits
     uint32_t depth = 0;
     bool is_leaf() const { return left < 0 && right < 0; }  // bloom_tree.rs:416-418
@@ -95,7 +96,10 @@ const KnobName KNOBS[] = {
     {"PFQ_BIN_BLOCKS", &Knobs::bin_blocks},     {"PFQ_TEST_BLOCKS", &Knobs::test_blocks},
     {"PFQ_TILE", &Knobs::tile},                 {"PFQ_TILE_COUNTS", &Knobs::tile_counts},
     {"PFQ_NO_TAIL_BATCH", &Knobs::no_tail_batch}, {"PFQ_BIN_NARROW", &Knobs::bin_narrow},
-    {"PFQ_BIN_WIDE", &Knobs::bin_wide},         {"PFQ_BIN_DEBUG", &Knobs::bin_debug},
+    {"PFQ_BIN_WIDE", &Knobs::bin_wide},
+#ifdef PFQ_EXPERIMENTS  // (timing experiments with wrong results: not in the library as shipped)
+    {"PFQ_BIN_DEBUG", &Knobs::bin_debug},
+#endif
     {"PFQ_BLOCK", &Knobs::block},
     {"PFQ_COARSE", &Knobs::coarse},             {"PFQ_COARSE_COLS", &Knobs::coarse_cols},
     {"PFQ_COARSE_PROBES", &Knobs::coarse_probes}, {"PFQ_GROUP_LOG2", &Knobs::group_log2},
@@ -117,7 +121,17 @@ Knobs knobs_from_env() {
 
 }  // namespace
 
+namespace {
+std::atomic<long> g_open_trees{0};
+void release_communicators();  // (the kept RCCL communicators go when the last tree of the process is closed)
+}  // namespace
+
 struct pfq_tree {
+    pfq_tree() { ++g_open_trees; }
+    pfq_tree(const pfq_tree &) = delete;
+    ~pfq_tree() {
+        if (--g_open_trees == 0) release_communicators();
+    }
     int device = 0;
     Knobs knobs = knobs_from_env();
     // ---- model
@@ -169,6 +183,9 @@ struct pfq_tree {
     DevBuf<uint32_t> d_S, d_col_row, d_guard_off, d_guard_col;
     DevBuf<uint32_t> d_owner, d_owner_sorted, d_gfail;  // trees with guard columns, bucketed path: leaf pair of every pair slot
     DevBuf<unsigned long long> d_counts;
+    // what the counters held when the tree was opened (BloomNode::mapped_reads stored in tree.bin), last reset, imported or
+    // reduced: the reductions over replicas / ranks add up counters - base, so that stored counts are not added once per replica
+    DevBuf<unsigned long long> d_counts_base, d_counts_delta;
     // ---- query scratch
     DevBuf<unsigned long long> d_stats, d_cursors;  // cursors: [0] hit, [1] pair, [2] tile entries, [3] lo: chunks, hi: flagged pairs, [4] long reads, [5] miss words, [6] dirty pairs, [7] lo: open pairs after the tile passes (thresholds < 1), [8] guard pairs, [9] k-mer miss bytes handed out
     DevBuf<uint32_t> d_entries, d_pair_chunk, d_leaf_chunk0, d_flag_list;  // LDS-tile certificates
@@ -278,6 +295,7 @@ int parse_node(Cur &c, pfq_tree &t, int32_t parent, uint32_t depth, int32_t &out
         t.nodes[v].tax_id = c.str();
     }
     t.nodes[v].mapped_reads = c.u64();
+    t.nodes[v].base_reads = t.nodes[v].mapped_reads;
     if (!c.ok) return fail(PFQ_ERR_FORMAT, "tree.bin: truncated BloomNode");
     out_idx = v;
     return PFQ_OK;
@@ -358,6 +376,8 @@ int sync_counts_to_nodes(pfq_tree &t) {
     std::vector<unsigned long long> h(t.leaves.size());
     HIP_TRY(hipMemcpy(h.data(), t.d_counts.p, h.size() * 8, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < h.size(); ++i) t.nodes[t.leaves[i]].mapped_reads = h[i];
+    HIP_TRY(hipMemcpy(h.data(), t.d_counts_base.p, h.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); ++i) t.nodes[t.leaves[i]].base_reads = h[i];
     return PFQ_OK;
 }
 
@@ -689,6 +709,10 @@ int build_layout(pfq_tree &t) {
     std::vector<unsigned long long> h(nl);
     for (size_t i = 0; i < nl; ++i) h[i] = t.nodes[t.leaves[i]].mapped_reads;
     HIP_TRY(hipMemcpy(t.d_counts.p, h.data(), nl * 8, hipMemcpyHostToDevice));
+    HIP_TRY(t.d_counts_base.ensure(nl));
+    HIP_TRY(t.d_counts_delta.ensure(nl));
+    for (size_t i = 0; i < nl; ++i) h[i] = t.nodes[t.leaves[i]].base_reads;
+    HIP_TRY(hipMemcpy(t.d_counts_base.p, h.data(), nl * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(t.d_S.p, 0, s_words * 4, nullptr));
     for (uint32_t g = 0; g < t.n_groups; ++g)
         HIP_TRY(hipMemsetAsync(t.d_S.p + (g + 1) * t.group_stride - t.rw, 0xff, t.rw * 4, nullptr));
@@ -2047,8 +2071,29 @@ int pfq_leaf_counts_import(pfq_tree *tree, const uint64_t *d_src, void *stream) 
     if (!tree || !d_src) return fail(PFQ_ERR_ARG, "null argument");
     PFQ_TRY(use_device(tree->device));
     PFQ_TRY(build_layout(*tree));
-    if (!tree->leaves.empty())
+    if (!tree->leaves.empty()) {
         HIP_TRY(hipMemcpyAsync(tree->d_counts.p, d_src, tree->leaves.size() * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        HIP_TRY(hipMemcpyAsync(tree->d_counts_base.p, d_src, tree->leaves.size() * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return PFQ_OK;
+}
+int pfq_leaf_counts_export_delta(pfq_tree *tree, uint64_t *d_dst, void *stream) {
+    if (!tree || !d_dst) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    PFQ_TRY(build_layout(*tree));
+    pfq::launch_counts_op(reinterpret_cast<unsigned long long *>(d_dst), tree->d_counts.p, tree->d_counts_base.p, (uint32_t)tree->leaves.size(), true,
+                          (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return PFQ_OK;
+}
+int pfq_leaf_counts_import_delta(pfq_tree *tree, const uint64_t *d_src, void *stream) {
+    if (!tree || !d_src) return fail(PFQ_ERR_ARG, "null argument");
+    PFQ_TRY(use_device(tree->device));
+    PFQ_TRY(build_layout(*tree));
+    const uint32_t nl = (uint32_t)tree->leaves.size();
+    pfq::launch_counts_op(tree->d_counts.p, tree->d_counts_base.p, reinterpret_cast<const unsigned long long *>(d_src), nl, false, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    if (nl) HIP_TRY(hipMemcpyAsync(tree->d_counts_base.p, tree->d_counts.p, (size_t)nl * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PFQ_OK;
 }
 // ---- several replicas behind one process: one RCCL all-reduce of the per-leaf counters -------------------------------
@@ -2068,8 +2113,10 @@ Rccl &rccl() {  // loaded once per process; RCCL is a run-time dependency of mul
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!r.handle) r.handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        // (RTLD_LOCAL: an embedding framework may bring an RCCL of its own — PyTorch does — and the two must not see each
+        // other's symbols)
+        r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!r.handle) r.handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!r.handle) {
             r.error = std::string("cannot load librccl: ") + dlerror();
             return;
@@ -2089,8 +2136,23 @@ Rccl &rccl() {  // loaded once per process; RCCL is a run-time dependency of mul
     return r;
 }
 thread_local uint32_t g_last_ranks = 0;
+// The communicator of a device set is made on first use and kept while the process has a tree open (a caller may reduce
+// after every block; ncclCommInitAll costs seconds).  Destroyed with the last tree — not at process exit, where the HIP
+// runtime and other users of it (an embedding framework) are already tearing down.
+std::mutex g_comm_mutex;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_comm_cache;
 }  // namespace
 }  // extern "C++"
+namespace {
+void release_communicators() {
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    if (g_comm_cache.empty()) return;
+    Rccl &r = rccl();
+    for (auto &kv : g_comm_cache)
+        for (auto c : kv.second) (void)r.CommDestroy(c);
+    g_comm_cache.clear();
+}
+}  // namespace
 
 uint32_t pfq_last_allreduce_ranks(void) { return g_last_ranks; }
 
@@ -2129,50 +2191,73 @@ int pfq_trees_allreduce_counts(pfq_tree *const *trees, uint32_t n_trees) {
     }
     const uint32_t nl = (uint32_t)trees[0]->leaves.size();
     if (n_trees == 1 || nl == 0) return PFQ_OK;
-    // (1) replicas that share a device: added into the device's first replica
+    // What a replica adds to the job is what it counted since it was opened (or last reduced): counters - base.  The stored
+    // mapped_reads of a database that was saved after a query are in every replica's base and must count once, as on one
+    // device and in the reference (query.rs:143 accumulates on the loaded value).
+    // (1) every replica's delta; replicas that share a device are added into the device's first replica
     for (auto &kv : by_dev) {
         HIP_TRY(hipSetDevice(kv.first));
-        for (size_t r = 1; r < kv.second.size(); ++r)
-            pfq::launch_add_counts(kv.second[0]->d_counts.p, kv.second[r]->d_counts.p, nl, nullptr);
+        for (size_t r = 0; r < kv.second.size(); ++r) {
+            pfq_tree &t = *kv.second[r];
+            pfq::launch_counts_op(t.d_counts_delta.p, t.d_counts.p, t.d_counts_base.p, nl, true, nullptr);
+            if (r) pfq::launch_counts_op(kv.second[0]->d_counts_delta.p, kv.second[0]->d_counts_delta.p, t.d_counts_delta.p, nl, false, nullptr);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
     // (2) one all-reduce (sum, u64[n_leaves]) over RCCL across the devices, in place in each device's first replica.
     // Replicas that all share one device need no communicator (loading librccl and ncclCommInitAll cost seconds);
     // PFQ_RCCL_ALWAYS=1 makes a one-rank communicator anyway, so that the RCCL path can be exercised on a one-GPU box.
+    // The communicator of a device set is made once per process and kept (a caller may reduce after every block).
     const char *always = getenv("PFQ_RCCL_ALWAYS");
     if (by_dev.size() > 1 || (always && atoi(always) != 0)) {
-    Rccl &r = rccl();
-    if (!r.error.empty()) return fail(PFQ_ERR_DEVICE, r.error);
-    std::vector<int> devs;
-    for (auto &kv : by_dev) devs.push_back(kv.first);
-    std::vector<ncclComm_t> comms(devs.size());
-    ncclResult_t rc = r.CommInitAll(comms.data(), (int)devs.size(), devs.data());
-    if (rc != ncclSuccess) return fail(PFQ_ERR_DEVICE, std::string("ncclCommInitAll: ") + r.GetErrorString(rc));
-    rc = r.GroupStart();
-    for (size_t i = 0; i < devs.size() && rc == ncclSuccess; ++i) {
-        (void)hipSetDevice(devs[i]);
-        unsigned long long *buf = by_dev[devs[i]][0]->d_counts.p;
-        rc = r.AllReduce(buf, buf, nl, ncclUint64, ncclSum, comms[i], nullptr);
+        Rccl &r = rccl();
+        if (!r.error.empty()) return fail(PFQ_ERR_DEVICE, r.error);
+        std::vector<int> devs;
+        for (auto &kv : by_dev) devs.push_back(kv.first);
+        auto &comm_cache = g_comm_cache;
+        std::lock_guard<std::mutex> lock(g_comm_mutex);  // (one collective of this process at a time)
+        auto it = comm_cache.find(devs);
+        if (it == comm_cache.end()) {
+            std::vector<ncclComm_t> fresh(devs.size());
+            const ncclResult_t rc0 = r.CommInitAll(fresh.data(), (int)devs.size(), devs.data());
+            if (rc0 != ncclSuccess) return fail(PFQ_ERR_DEVICE, std::string("ncclCommInitAll: ") + r.GetErrorString(rc0));
+            it = comm_cache.emplace(devs, std::move(fresh)).first;
+        }
+        std::vector<ncclComm_t> &comms = it->second;
+        ncclResult_t rc = r.GroupStart();
+        for (size_t i = 0; i < devs.size() && rc == ncclSuccess; ++i) {
+            (void)hipSetDevice(devs[i]);
+            unsigned long long *buf = by_dev[devs[i]][0]->d_counts_delta.p;
+            rc = r.AllReduce(buf, buf, nl, ncclUint64, ncclSum, comms[i], nullptr);
+        }
+        const ncclResult_t rc_end = r.GroupEnd();
+        if (rc == ncclSuccess) rc = rc_end;
+        hipError_t he = hipSuccess;
+        for (size_t i = 0; i < devs.size(); ++i) {
+            (void)hipSetDevice(devs[i]);
+            const hipError_t e = hipDeviceSynchronize();
+            if (he == hipSuccess) he = e;
+        }
+        if (rc != ncclSuccess || he != hipSuccess) {  // a communicator that failed is not reused
+            for (auto c : comms) (void)r.CommDestroy(c);
+            comm_cache.erase(it);
+        }
+        if (rc != ncclSuccess) return fail(PFQ_ERR_DEVICE, std::string("ncclAllReduce: ") + r.GetErrorString(rc));
+        if (he != hipSuccess) return fail(PFQ_ERR_DEVICE, std::string("all-reduce of the leaf counters: ") + hipGetErrorString(he));
+        g_last_ranks = (uint32_t)devs.size();
     }
-    const ncclResult_t rc_end = r.GroupEnd();
-    if (rc == ncclSuccess) rc = rc_end;
-    hipError_t he = hipSuccess;
-    for (size_t i = 0; i < devs.size(); ++i) {
-        (void)hipSetDevice(devs[i]);
-        const hipError_t e = hipDeviceSynchronize();
-        if (he == hipSuccess) he = e;
-    }
-    for (auto c : comms) (void)r.CommDestroy(c);
-    if (rc != ncclSuccess) return fail(PFQ_ERR_DEVICE, std::string("ncclAllReduce: ") + r.GetErrorString(rc));
-    if (he != hipSuccess) return fail(PFQ_ERR_DEVICE, std::string("all-reduce of the leaf counters: ") + hipGetErrorString(he));
-    g_last_ranks = (uint32_t)devs.size();
-    }
-    // (3) the totals go back to the other replicas of each device
+    // (3) every replica: counters = its base + the job's delta, and that is its new base (a second call changes nothing)
     for (auto &kv : by_dev) {
         HIP_TRY(hipSetDevice(kv.first));
-        for (size_t q = 1; q < kv.second.size(); ++q)
-            HIP_TRY(hipMemcpy(kv.second[q]->d_counts.p, kv.second[0]->d_counts.p, (size_t)nl * 8, hipMemcpyDeviceToDevice));
+        const unsigned long long *total = kv.second[0]->d_counts_delta.p;
+        for (size_t q = 0; q < kv.second.size(); ++q) {
+            pfq_tree &t = *kv.second[q];
+            pfq::launch_counts_op(t.d_counts.p, t.d_counts_base.p, total, nl, false, nullptr);
+            HIP_TRY(hipMemcpyAsync(t.d_counts_base.p, t.d_counts.p, (size_t)nl * 8, hipMemcpyDeviceToDevice, nullptr));
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
     }
     return PFQ_OK;
 }
@@ -2182,8 +2267,11 @@ int pfq_leaf_counts_reset(pfq_tree *tree) {
     PFQ_TRY(use_device(tree->device));
     PFQ_TRY(build_layout(*tree));
     HIP_TRY(hipDeviceSynchronize());
-    if (!tree->leaves.empty()) HIP_TRY(hipMemset(tree->d_counts.p, 0, tree->leaves.size() * 8));
-    for (auto &nd : tree->nodes) nd.mapped_reads = 0;
+    if (!tree->leaves.empty()) {
+        HIP_TRY(hipMemset(tree->d_counts.p, 0, tree->leaves.size() * 8));
+        HIP_TRY(hipMemset(tree->d_counts_base.p, 0, tree->leaves.size() * 8));
+    }
+    for (auto &nd : tree->nodes) nd.mapped_reads = nd.base_reads = 0;
     return PFQ_OK;
 }
 

@@ -18,6 +18,13 @@ namespace pfq {
 
 // Per-wave reservations in the deferred-pair buffer (slots) and in the miss-word buffer (u64 words): every wave of every
 // classify launch may leave one of each partly used, which the host adds to the buffers' sizes.
+// Experiment switches of k_tile_bin that give wrong results are compiled in with -DPFQ_EXPERIMENTS only: no environment
+// variable or option can change the results of the library as shipped.
+#ifdef PFQ_EXPERIMENTS
+#define PFQ_DEBUG_BITS(a) ((a).debug)
+#else
+#define PFQ_DEBUG_BITS(a) 0u
+#endif
 constexpr uint32_t PAIR_RESERVE = 32, MISS_RESERVE = 256;
 enum StatSlot { ST_CANDIDATES = 0, ST_HITS = 1, ST_ALLHIT = 2, ST_ALG_BYTES = 3, ST_DEFERRED = 4, ST_LISTED = 5 /* (read, leaf group) entries of a two-level frontier */, ST_N = 8 };
 
@@ -215,7 +222,8 @@ struct TileArgs {
     const uint32_t *bucket_off;  // [(n_leaves << sub_log2) + 1]
     uint32_t sub_log2, n_leaves, n_tiles;   // n_leaves: buckets = leaf + guard columns
     uint32_t bin_shape;          // 0 auto, 1 force the 8 x 128 build of k_tile_bin, 2 force 16 x 256
-    uint32_t debug;              // timing experiments only (results wrong): 1 no bucket stores, 2 no LDS binning, 4 no record loads
+    uint32_t debug;              // builds with -DPFQ_EXPERIMENTS only (timing experiments, results wrong): 1 no bucket stores, 2 no LDS binning,
+                                 // 8 / 16 block mode without the flags of full bins / full buckets.  The default build ignores the field.
     ChunkDesc *chunks;           // [max_chunks]
     uint32_t max_chunks;
     uint32_t *leaf_chunk0;       // [n_leaves + 1] first chunk of each leaf (chunks of a leaf are contiguous)
@@ -298,8 +306,9 @@ void launch_superset(const uint64_t *bits, uint64_t n_words, const uint32_t *d_e
                      uint32_t *d_fail, hipStream_t st);
 void launch_transpose(const uint64_t *bits, uint64_t n_words, const uint32_t *d_col_row, uint32_t n_cols, uint32_t *S,
                       uint32_t rw, uint64_t group_stride, uint32_t group_log2, hipStream_t st);
-// dst[i] += src[i] (u64 counters; replicas of one tree on the same device, pfq_trees_allreduce_counts)
-void launch_add_counts(unsigned long long *dst, const unsigned long long *src, uint32_t n, hipStream_t st);
+// dst[i] = a[i] + b[i], or a[i] - b[i] (u64 counters; the count reductions over replicas / ranks work on what a replica
+// counted since it was opened: counters - base)
+void launch_counts_op(unsigned long long *dst, const unsigned long long *a, const unsigned long long *b, uint32_t n, bool subtract, hipStream_t st);
 void launch_debug_indices(const HashParams &hp, const uint8_t *d_seq, uint64_t len, uint64_t *d_out, hipStream_t st);
 void launch_synth_genomes(uint8_t *d_out, uint64_t n_genomes, uint64_t genome_len, uint64_t seed_base, hipStream_t st);
 void launch_synth_reads(uint8_t *d_out, uint64_t first, uint64_t n_reads, uint64_t read_len, const uint8_t *d_genomes,

@@ -1848,7 +1848,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
             bool valid_n[WPI];
             load_recs(nxt, rec_n, local_n, valid_n);
             m_nxt = load_meta(nxt.partial ? nxt.p : nxt.p + nxt.P);
-            if (!(a.debug & 2u)) {
+            if (!(PFQ_DEBUG_BITS(a) & 2u)) {
                 RecordIter1 rit[WPI];
                 uint32_t cbase[WPI];  // counter index of tile 0 for this lane
 #pragma unroll
@@ -1871,7 +1871,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                     if (BLK) {  // (block mode: exactly the pairs whose probe found its bin full take the fallback — each costs 8 x 1300 line gathers there)
 #pragma unroll
                         for (uint32_t u = 0; u < WPI; ++u)
-                            if (valid[u] && slot[u] >= BIN_CAP && !(a.debug & 8u)) flag_fallback(a, dsc.first + (local[u] >> TL));
+                            if (valid[u] && slot[u] >= BIN_CAP && !(PFQ_DEBUG_BITS(a) & 8u)) flag_fallback(a, dsc.first + (local[u] >> TL));
                     }
                 };
                 uint32_t ix[WPI];
@@ -1923,7 +1923,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                 const uint32_t room = pos < dsc.cap ? dsc.cap - pos : 0u, wr = c4 < room ? c4 : room;
                 uint32_t *dst = bucket0 + (uint64_t)(have ? t : 0u) * dsc.cap + pos;
                 constexpr uint32_t FB = BIN_CAP < 128 ? 2 : 5;  // 16-byte reads in flight per lane: two batches cover a full bin (516 entries / 64)
-                const uint32_t wr_eff = (a.debug & 1u) ? 0u : wr;
+                const uint32_t wr_eff = (PFQ_DEBUG_BITS(a) & 1u) ? 0u : wr;
                 for (uint32_t i0 = sl * 4u; i0 < wr; i0 += STEP * FB) {
                     uint4 v[FB];
 #pragma unroll
@@ -1945,7 +1945,7 @@ __global__ void __launch_bounds__(BIN_WAVES * 64) k_tile_bin(TileArgs a) {
                     for (uint32_t u = 0; u < FB; ++u)
                         if (i0 + u * STEP < wr_eff) *reinterpret_cast<uint4 *>(dst + i0 + u * STEP) = v[u];
                 }
-                if (!COUNTS && !(a.debug & 16u))
+                if (!COUNTS && !(PFQ_DEBUG_BITS(a) & 16u))
                     for (uint32_t i = wr + sl; i < cc; i += LPT) flag_fallback(a, dsc.first + (row[i] >> TL));
                 if (!BLK && (cn > BIN_CAP || (COUNTS && wr < cc))) {  // the LDS bin (or, with k-mer entries, the bucket) overflowed: whose probes were lost is unknown
                     for (uint32_t i = sl; i < flush_P; i += LPT) flag_fallback(a, dsc.first + flush_p + i);
@@ -2230,7 +2230,6 @@ __global__ void __launch_bounds__(1024) k_tile_test(TileArgs a) {
         __syncthreads();
     }
     while (true) {
-        const uint32_t leaf = (uint32_t)(task / a.n_tiles), t = (uint32_t)(task % a.n_tiles);
         // the next unit: the column's next group (it may turn out empty), else the first group of the block's next task
         const bool more = s_misc[buf][0] == TG;  // (block-uniform)
         const uint64_t ntask = more ? task : valid_task(task + gridDim.x);
@@ -2747,12 +2746,12 @@ __global__ void __launch_bounds__(256) k_transpose(const uint64_t *bits, uint64_
         }
     }
 }
-__global__ void __launch_bounds__(256) k_add_counts(unsigned long long *dst, const unsigned long long *src, uint32_t n) {
+__global__ void __launch_bounds__(256) k_counts_op(unsigned long long *dst, const unsigned long long *a, const unsigned long long *b, uint32_t n, int sub) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] += src[i];
+    if (i < n) dst[i] = sub ? a[i] - b[i] : a[i] + b[i];
 }
-void launch_add_counts(unsigned long long *dst, const unsigned long long *src, uint32_t n, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_add_counts, dim3((n + 255) / 256), dim3(256), 0, st, dst, src, n);
+void launch_counts_op(unsigned long long *dst, const unsigned long long *a, const unsigned long long *b, uint32_t n, bool subtract, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_counts_op, dim3((n + 255) / 256), dim3(256), 0, st, dst, a, b, n, subtract ? 1 : 0);
 }
 void launch_transpose(const uint64_t *bits, uint64_t n_words, const uint32_t *d_col_row, uint32_t n_cols, uint32_t *S,
                       uint32_t rw, uint64_t group_stride, uint32_t group_log2, hipStream_t st) {

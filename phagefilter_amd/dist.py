@@ -41,11 +41,13 @@ def reduce_tree_counts(tree, device=None, stream: int = 0):
     import torch
     n = int(tree.info().n_leaves)
     buf = torch.zeros(max(n, 1), dtype=torch.int64, device=device if device is not None else f"cuda:{tree.device}")
-    tree.export_counts(buf.data_ptr(), stream)
+    torch.cuda.current_stream().synchronize()   # the fill (torch's stream) before the export (the raw stream) writes the buffer
+    # what THIS rank counted (counters - what the database was opened with): stored counts must not be added once per rank
+    tree.export_counts_delta(buf.data_ptr(), stream)
     _sync_stream(stream)          # the copy must have landed before the collective (another stream) reads the buffer
     all_reduce_counts(buf)
     torch.cuda.current_stream().synchronize()
-    tree.import_counts(buf.data_ptr(), stream)
+    tree.import_counts_delta(buf.data_ptr(), stream)   # counters = stored + the job's new counts, on every rank
     _sync_stream(stream)
     return buf
 
@@ -55,10 +57,12 @@ def check_disjoint_shards(first: int, n: int, total: int) -> None:
     all-gather of the (first, n) pairs, checked on every rank.  No-op without a process group."""
     import torch
     import torch.distributed as dist
-    if not 0 <= first <= first + n <= total:
-        raise ValueError(f"shard range [{first}, {first + n}) outside the tree's {total} leaves")
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if not 0 <= first <= first + n <= total:
+            raise ValueError(f"shard range [{first}, {first + n}) outside the tree's {total} leaves")
         return
+    # gather first, validate afterwards: every rank sees every span and raises (or not) together — a rank that left
+    # before the collective would leave the others waiting in it
     mine = torch.tensor([first, n, total], dtype=torch.int64)
     if dist.get_backend() == "nccl":
         mine = mine.cuda()
@@ -67,6 +71,9 @@ def check_disjoint_shards(first: int, n: int, total: int) -> None:
     spans = sorted((int(s[0]), int(s[1]), int(s[2])) for s in spans)
     if any(s[2] != total for s in spans):
         raise ValueError(f"ranks disagree on the tree's leaf count: {spans}")
+    for f0, fn, ft in spans:
+        if not 0 <= f0 <= f0 + fn <= ft:
+            raise ValueError(f"shard range [{f0}, {f0 + fn}) outside the tree's {ft} leaves")
     for (a0, an, _), (b0, _, _) in zip(spans, spans[1:]):
         if an and a0 + an > b0:
             raise ValueError(f"shard leaf ranges overlap: {spans}")
@@ -95,6 +102,7 @@ def gather_shard_counts(tree, device=None, stream: int = 0):
     dev = device if device is not None else f"cuda:{tree.device}"
     local = torch.zeros(n, dtype=torch.int64, device=dev)
     if n:
+        torch.cuda.current_stream().synchronize()   # the fill before the export on the raw stream
         tree.export_counts(local.data_ptr(), stream)
         _sync_stream(stream)
     return pad_and_reduce(local, first, total)

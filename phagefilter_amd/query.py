@@ -223,6 +223,14 @@ class BloomTree:
     def import_counts(self, d_src: int, stream: int = 0) -> None:
         _ffi.check(_ffi.lib().pfq_leaf_counts_import(self._h, d_src, stream))
 
+    def export_counts_delta(self, d_dst: int, stream: int = 0) -> None:
+        """What this replica counted since it was opened / last reset, imported or reduced (counters - base)."""
+        _ffi.check(_ffi.lib().pfq_leaf_counts_export_delta(self._h, d_dst, stream))
+
+    def import_counts_delta(self, d_src: int, stream: int = 0) -> None:
+        """counters = base + d_src (the sum of the ranks' deltas); that becomes the new base."""
+        _ffi.check(_ffi.lib().pfq_leaf_counts_import_delta(self._h, d_src, stream))
+
 
 def query_batch(bloom_tree: BloomTree, read_set: Sequence[bytes], threshold: float,
                 result_map: Optional[ResultMap] = None, read_ids: Optional[Sequence[str]] = None) -> BloomTree:

@@ -331,6 +331,34 @@ def test_cli_devices_two_replicas_equal_single_device(cli_db, tmp_path, filterin
 
 
 @pytest.mark.gpu
+def test_cli_devices_on_a_database_with_stored_counts(cli_db, tmp_path):
+    """`query --devices 0,0` on a database whose tree.bin holds non-zero mapped_reads (saved after a query): the stored
+    counts are reported once, as on one device (replicas x stored before)."""
+    import shutil
+    from phagefilter_amd import BloomTree, pack_reads
+    db = str(tmp_path / "db_counted")
+    shutil.copytree(cli_db, db)
+    t = BloomTree.load(db)
+    reads = [s.encode() for _, s, _ in example_reads()][:300]
+    seq, off = pack_reads(reads)
+    t.query_packed(seq, off, 0.7)
+    assert sum(c for _, c in t.get_leaf_counts()) > 0
+    t.save(db)
+    t.close()
+    base = [CLI, "query", "--reads", os.path.join(EX, "reads"), "--db-path", db, "--filter-threshold", "0.7", "--threads", "4"]
+    env = dict(os.environ, PFQ_INGEST_CHUNK_BYTES="20000")
+    outs = {}
+    for name, extra in (("one", []), ("two", ["--devices", "0,0"])):
+        out = str(tmp_path / name)
+        p = subprocess.run(base + ["--out", out] + extra, capture_output=True, text=True, env=env)
+        assert p.returncode == 0, p.stderr
+        outs[name] = open(os.path.join(out, "CLASSIFICATION.csv")).read()
+    gold = json.load(open(os.path.join(EX, "expected.json")))
+    assert outs["one"] != gold["expected"]["0.7"]["classification_csv"]    # the stored counts are in
+    assert outs["two"] == outs["one"]
+
+
+@pytest.mark.gpu
 def test_cli_block_size_zero_processes_nothing(cli_db, tmp_path):
     """--block-size-reads 0: the reference's first block is empty (file_parser.rs:252-270), its loop never runs
     (main.rs:334-368): outputs are created empty, nothing is parsed — not even a malformed file is noticed."""

@@ -243,6 +243,71 @@ def test_replicas_on_one_device_allreduce_to_single_tree_counts(gpu):
         t.close()
 
 
+def test_replicas_of_a_database_with_stored_counts(gpu, tmp_path):
+    """A database saved after a query holds non-zero mapped_reads (pfq_tree_save writes the live counters back); the
+    reference accumulates on the loaded value (query.rs:143).  Replicas of it must report stored + new — not
+    replicas x stored + new — and reducing twice must change nothing."""
+    genomes = [rand_dna(600) for _ in range(7)]
+    ot, ids = oracle_tree(genomes, 21, 60013, 6)
+    reads = make_reads(genomes, 300, 60, 150, 21)
+    first, second = reads[:200], reads[200:]
+    gt = gpu_tree(genomes, ids, 21, 60013, 6)
+    seq, off = pack_reads(first)
+    gt.query_packed(seq, off, 0.8)
+    d = str(tmp_path / "db")
+    gt.save(d)                                                    # mapped_reads of `first` are in tree.bin now
+    gt.close()
+    orc.query_batch(ot, first, 0.8, want_hits=False)
+    stored = ot.leaf_counts()
+    assert sum(c for _, c in stored) > 50
+    orc.query_batch(ot, second, 0.8, want_hits=False)            # the oracle goes on counting on the same tree
+    want = ot.leaf_counts()
+    reps = [BloomTree.load(d) for _ in range(3)]
+    for rep in reps:
+        assert rep.get_leaf_counts() == stored
+    cuts = [0, 40, 41, len(second)]
+    for rep, a, b in zip(reps, cuts, cuts[1:]):
+        seq, off = pack_reads(second[a:b])
+        rep.query_packed(seq, off, 0.8)
+    allreduce_counts(reps)
+    for rep in reps:
+        assert rep.get_leaf_counts() == want                      # stored once + every replica's new counts
+    allreduce_counts(reps)                                        # again, no new queries: nothing changes
+    for rep in reps:
+        assert rep.get_leaf_counts() == want
+    # the layout is rebuilt in between (a knob of the layout): what a replica counted since the last reduction survives
+    extra = reads[:30]
+    seq, off = pack_reads(extra)
+    reps[1].query_packed(seq, off, 0.8)
+    reps[1].set_option("PFQ_COARSE", "0")
+    orc.query_batch(ot, extra, 0.8, want_hits=False)
+    allreduce_counts(reps)
+    for rep in reps:
+        assert rep.get_leaf_counts() == ot.leaf_counts()
+    # the multi-process hooks: deltas out, sum in
+    from hipbuf import DeviceBuffer, synchronize
+    n = len(ids)
+    seq, off = pack_reads(reads[:25])
+    reps[0].query_packed(seq, off, 0.8)
+    reps[2].query_packed(seq, off, 0.8)
+    orc.query_batch(ot, reads[:25], 0.8, want_hits=False)
+    orc.query_batch(ot, reads[:25], 0.8, want_hits=False)
+    bufs = [DeviceBuffer(8 * n) for _ in reps]
+    for rep, b in zip(reps, bufs):
+        rep.export_counts_delta(b.ptr)
+    synchronize()
+    deltas = [b.to_numpy(np.uint64) for b in bufs]
+    assert int(deltas[1].sum()) == 0 and int(deltas[0].sum()) == int(deltas[2].sum()) > 0
+    total = DeviceBuffer.from_numpy(deltas[0] + deltas[1] + deltas[2])
+    for rep in reps:
+        rep.import_counts_delta(total.ptr)
+    synchronize()
+    for rep in reps:
+        assert rep.get_leaf_counts() == ot.leaf_counts()
+    for rep in reps:
+        rep.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # related genomes: a read passes many leaves (what a phage database is)
 # ---------------------------------------------------------------------------------------------------------------
