@@ -82,7 +82,7 @@ struct Knobs {
     long long record_gb = -1, tile_gb = -1, tile_entries = -1, slice_kb = -1;
     long long verify_blocks = -1, verify_chunk = -1, verify_sub = -1, verify_threads = -1, bin_blocks = -1, test_blocks = -1;
     long long tile = -1, tile_counts = -1, no_tail_batch = -1, bin_narrow = -1, bin_wide = -1, bin_debug = -1, block = -1;
-    long long coarse = -1, coarse_cols = -1, coarse_probes = -1, group_log2 = -1;
+    long long coarse = -1, coarse_cols = -1, coarse_probes = -1, group_log2 = -1, screen_recs = -1;
 };
 struct KnobName {
     const char *name;
@@ -103,6 +103,7 @@ const KnobName KNOBS[] = {
     {"PFQ_BLOCK", &Knobs::block},
     {"PFQ_COARSE", &Knobs::coarse},             {"PFQ_COARSE_COLS", &Knobs::coarse_cols},
     {"PFQ_COARSE_PROBES", &Knobs::coarse_probes}, {"PFQ_GROUP_LOG2", &Knobs::group_log2},
+    {"PFQ_SCREEN_RECS", &Knobs::screen_recs},
 };
 bool set_knob(Knobs &k, const char *name, const char *value) {
     for (const KnobName &kn : KNOBS)
@@ -1003,6 +1004,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 128 * 4, st));
                 a.batch_tails = (recs && !counts_mode && kn.no_tail_batch <= 0) ? 1u : 0u;
                 a.block_pairs = block_mode ? 1u : 0u;
+                a.screen_recs = kn.screen_recs >= 0 ? (uint32_t)(kn.screen_recs != 0) : 1u;
                 if (block_mode) {
                     if (!t.tables_valid) {  // (the leaf set changed, or first use)
                         pfq::launch_block_tables(t.d_bits.p, t.n_words, t.d_col_row.p, (uint32_t)nl, t.d_T.p, st);

@@ -369,11 +369,15 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
 // MULTI (the coarse level of a two-level frontier): a k-mer is a definite miss for a column if ANY of its first n_probes
 // probed bits is 0 (1 .. 4; the filters of internal nodes are too full for one bit to tell), and the screen looks at
 // scr_extra k-mers beyond maxmiss + 1 instead of SCREEN_EXTRA.
-template <uint32_t P, uint32_t LPR_LOG2, bool MULTI = false>  // counter planes; log2 of the lanes per read (rw = 4 << LPR_LOG2: 16, 32 or 64)
+// RECS (the launches that defer survivors to the bucketed certificate stage): the screen hashes most k-mers of a read that
+// survives anyway, so it leaves their probe records behind — recs[read offset + k-mer] — and `n_rec` returns how many k-mers
+// from the read's first on have theirs; the per-read path then only hashes what is left (the survivors were hashed twice
+// before: ~10 of 25 ms at threshold 0.3).  Reads that die cost a few 16-byte stores each.
+template <uint32_t P, uint32_t LPR_LOG2, bool MULTI = false, bool RECS = false>  // counter planes; log2 of the lanes per read (rw = 4 << LPR_LOG2: 16, 32 or 64)
 __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const uint8_t *comp, uint32_t *live_out,
                                              const QueryArgs &a, const uint32_t *list, uint64_t r0, uint32_t n_in_group,
                                              uint32_t &survive, uint32_t &irregular, uint64_t &lane_len, uint64_t &rid,
-                                             uint32_t n_probes = 1, uint32_t scr_extra = SCREEN_EXTRA) {
+                                             uint32_t &n_rec, uint32_t n_probes = 1, uint32_t scr_extra = SCREEN_EXTRA) {
     const uint32_t lane = lane_id(), k = a.hp.k;
     static_assert(LPR_LOG2 >= 2 && LPR_LOG2 <= 4, "rows of 16, 32 or 64 words");
     constexpr uint32_t lpr_log2 = LPR_LOG2, lpr = 1u << lpr_log2, rpw = 64u >> lpr_log2, rw = 4u << lpr_log2;
@@ -438,6 +442,8 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
     const uint32_t stride = (DENSE_READS / rpw) * MINI_BYTES;  // bytes of LDS per read and direction (rpw <= 16)
     const uint32_t base = j * stride + WIN_PAD;
     bool alive = regular;  // my read still has a live leaf
+    n_rec = 0;
+    const bool rec_ok = RECS && a.screen_recs && a.recs != nullptr && regular && o0 + n64 <= a.rec_cap;  // (room for all the read's records, as the per-read path asks)
     // The bytes of a read are staged a segment at a time — as many k-mers as the read's share of the LDS holds, 128 of a
     // 150 bp read at k = 21 — so that a pass needs no global load of its own (a round trip per pass of eight k-mers before).
     const uint32_t seg_cap = stride - 2u * WIN_PAD;
@@ -476,6 +482,10 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
         const bool valid = q < nk;
         uint64_t h1, h2;
         kmer_hashes_at(fw, rw_, base + x, base + (W - x - k), valid, a.hp, h1, h2);
+        if (RECS) {
+            if (rec_ok && valid) a.recs[o0 + pos + q] = make_probe_record(h1, h2, a.hp);
+            if (rec_ok && active && pos == n_rec) n_rec = pos + nk;  // (contiguous from the first k-mer on: passes after a pause do not count)
+        }
         // row indices of the wave go through LDS (live_out is free until the end): a lane fetches the eight of its
         // read with two 16-byte reads; k-mers that do not exist point at the all-ones row behind S (no miss)
         if (MULTI) {  // probe p of the wave's k-mers at live_out[64 p ..]
@@ -625,7 +635,8 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
     uint32_t pair_used = PAIR_CHUNK;
     uint32_t miss_left = 0;  // thresholds < 1: miss words this wave may still hand out (reserved MISS_RESERVE at a time)
 
-    auto process_read = [&](uint64_t r, const uint32_t *pre) {  // pre: frontier words from the dense counting screen
+    // pre: frontier words from the dense screen; n_done: k-mers (from the first on) whose probe records the screen wrote
+    auto process_read = [&](uint64_t r, const uint32_t *pre, uint32_t n_done = 0) {
         const uint64_t o0 = a.off[r], L = a.off[r + 1] - o0;
         ReadCtx rc;
         rc.read = a.seq + o0;
@@ -710,7 +721,7 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
                         // 150 bp reads at k = 20..23 have 128 + (1..3) k-mers: a third hashing pass for two or three
                         // k-mers.  Such last windows are left to k_tail_records (four reads per pass).
                         const bool split_tail = a.batch_tails && has_batched_tail(rc.n);
-                        for (uint64_t base = 0; base < rc.n; base += WIN_KMERS) {
+                        for (uint64_t base = n_done; base < rc.n; base += WIN_KMERS) {
                             uint32_t cnt = (uint32_t)((rc.n - base) < WIN_KMERS ? (rc.n - base) : WIN_KMERS);
                             if (split_tail && base + WIN_KMERS > rc.n) break;
                             uint64_t h1 = w0_h1, h2 = w0_h2;
@@ -783,15 +794,16 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
             const uint64_t r0 = g * rpw;
             const uint32_t cnt = (uint32_t)(n_work - r0 < rpw ? n_work - r0 : rpw);
             uint64_t lane_len, rid;
-            uint32_t survive, irregular;
-            dense_counts<8, LPR_LOG2>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, read_list, r0, cnt, survive,
-                                      irregular, lane_len, rid);
+            uint32_t survive, irregular, n_rec;
+            dense_counts<8, LPR_LOG2, false, DEFER>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, read_list, r0, cnt, survive,
+                                                    irregular, lane_len, rid, n_rec);
             if (!(((survive | irregular) >> (lane >> lpr_log2)) & 1u)) dense_bytes += lane_len;
             const uint32_t rid_lo = (uint32_t)rid;  // reads are indexed with 31 bits (query_device checks)
             while (survive) {
                 const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
                 survive &= survive - 1u;
-                process_read(LIST ? (uint64_t)bcast_u32(rid_lo, (int)(jj << lpr_log2)) : r0 + jj, dlds.live[wave] + jj * rw);
+                process_read(LIST ? (uint64_t)bcast_u32(rid_lo, (int)(jj << lpr_log2)) : r0 + jj, dlds.live[wave] + jj * rw,
+                             DEFER ? bcast_u32(n_rec, (int)(jj << lpr_log2)) : 0u);
             }
             while (irregular) {
                 const uint32_t jj = (uint32_t)__ffs((int)irregular) - 1u;
@@ -807,15 +819,15 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
             const uint64_t r0 = g * rpw;
             const uint32_t cnt = (uint32_t)(n_long - r0 < rpw ? n_long - r0 : rpw);
             uint64_t lane_len, rid;
-            uint32_t survive, irregular;
-            dense_counts<NPLANES, LPR_LOG2>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, a.long_list, r0, cnt,
-                                            survive, irregular, lane_len, rid);
+            uint32_t survive, irregular, n_rec;
+            dense_counts<NPLANES, LPR_LOG2, false, DEFER>(dlds.mini[wave][0], dlds.mini[wave][1], lds.comp, dlds.live[wave], a, a.long_list, r0, cnt,
+                                                          survive, irregular, lane_len, rid, n_rec);
             if (!(((survive | irregular) >> (lane >> lpr_log2)) & 1u)) dense_bytes += lane_len;
             const uint32_t rid_lo = (uint32_t)rid;  // reads are indexed with 31 bits (query_device checks)
             while (survive) {
                 const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
                 survive &= survive - 1u;
-                process_read(bcast_u32(rid_lo, (int)(jj << lpr_log2)), dlds.live[wave] + jj * rw);
+                process_read(bcast_u32(rid_lo, (int)(jj << lpr_log2)), dlds.live[wave] + jj * rw, DEFER ? bcast_u32(n_rec, (int)(jj << lpr_log2)) : 0u);
             }
             while (irregular) {
                 const uint32_t jj = (uint32_t)__ffs((int)irregular) - 1u;
@@ -999,10 +1011,10 @@ __global__ void __launch_bounds__(256, 2) k_coarse(QueryArgs a, CoarseArgs ca) {
             const uint64_t r0 = g * rpw;
             const uint32_t cnt = (uint32_t)(n_work - r0 < rpw ? n_work - r0 : rpw);
             uint64_t lane_len, rid;
-            uint32_t survive, irregular;
+            uint32_t survive, irregular, n_rec;
             dense_counts<LONG ? NPLANES : 8, LPR_LOG2, true>(dlds.mini[wave][0], dlds.mini[wave][1], s_comp, dlds.live[wave], a,
                                                             LONG ? a.long_list : nullptr, r0, cnt, survive, irregular, lane_len, rid,
-                                                            ca.n_probes, ca.scr_extra);
+                                                            n_rec, ca.n_probes, ca.scr_extra);
             if (!LONG) dense_bytes += lane_len;  // (the first launch saw every read)
             finish_group(survive, irregular, (uint32_t)rid, lpr_log2);
         }
