@@ -75,7 +75,8 @@ def _oracle_hits(ot, seq, off, thr):
 
 def _compare(gt, ot, seq, off, thr, variants):
     want_counts, want_hits = _oracle_hits(ot, seq, off, thr)
-    assert len(want_hits) > 0.3 * (len(off) - 1)                   # nearly every read that stems from a genome hits
+    # below threshold 1 nearly every read that stems from a genome hits; at 1.0 the error-free ones do (0.99^150 = 22 %)
+    assert len(want_hits) > (0.3 if thr < 1 else 0.08) * (len(off) - 1)
     out = {}
     for name, opts, expect_tile_mode in variants:
         for key, val in opts.items():
@@ -132,7 +133,8 @@ def test_config3_geometry_families_of_8_vs_oracle(gpu):
     seq, off = _reads(genomes, rng, N_READS, 0.01)
     for thr in (0.3, 1.0):
         want_counts, want_hits = _oracle_hits(ot, seq, off, thr)
-        assert len(want_hits) > 1.5 * (N_READS // 2)               # several strains per read
+        # several strains per read below threshold 1; at 1.0 the strains that are identical over an error-free read
+        assert len(want_hits) > (1.5 if thr < 1 else 0.4) * (N_READS // 2)
         for name, opts in (("first-call", {}), ("block", {"PFQ_BLOCK": "1"}), ("second-call", {})):
             for key, val in opts.items():
                 gt.set_option(key, val)

@@ -3,5 +3,6 @@
 set -o pipefail
 tag=${1:-x}; shift
 o=gpurun_out; mkdir -p $o
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu "$@" > $o/${tag}_pytest.log 2>&1
+if [ $# -gt 0 ] && [ -e "$1" ]; then T=""; else T="tests"; fi
+timeout -k 10 1100 python -m pytest $T -x -q -m gpu "$@" > $o/${tag}_pytest.log 2>&1
 rc=$?; tail -8 $o/${tag}_pytest.log; exit $rc
