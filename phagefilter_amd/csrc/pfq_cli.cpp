@@ -9,6 +9,7 @@
 #include <dirent.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -33,9 +34,27 @@
 #include <string_view>
 #include <vector>
 
+#include <emmintrin.h>  // SSE2 (x86-64 baseline)
+#include <functional>
+
 #include "../../include/pfq.h"
 
 namespace {
+
+// dst[i] = ASCII upper case of src[i] (what `to_uppercase` does to a nucleotide string, main.rs:347-349), 16 bytes at a time
+inline void copy_upper(char *dst, const uint8_t *src, size_t n) {
+    const __m128i lo = _mm_set1_epi8('a' - 1), hi = _mm_set1_epi8('z' + 1), bit = _mm_set1_epi8(0x20);
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i));
+        const __m128i m = _mm_and_si128(_mm_cmpgt_epi8(v, lo), _mm_cmplt_epi8(v, hi));  // (bytes >= 0x80 are negative: no letters)
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(dst + i), _mm_sub_epi8(v, _mm_and_si128(m, bit)));
+    }
+    for (; i < n; ++i) {
+        const uint8_t ch = src[i];
+        dst[i] = (char)((ch >= 'a' && ch <= 'z') ? ch - 32 : ch);
+    }
+}
 
 [[noreturn]] void die(const std::string &msg) {  // the reference panics: message on stderr, exit code 101
     fprintf(stderr, "phage_filter: %s\n", msg.c_str());
@@ -201,6 +220,11 @@ struct HostAlloc {
     template <class U>
     HostAlloc(const HostAlloc<U> &) {}
     static bool pinned(size_t n) { return g_pinned && n * sizeof(T) >= (1u << 20); }
+    // resize() without a fill: new elements are default-initialised (bytes and offsets are overwritten right away)
+    template <class U>
+    void construct(U *p) { ::new ((void *)p) U; }
+    template <class U, class A0, class... A>
+    void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
     T *allocate(size_t n) {
         void *p = nullptr;
         if (pinned(n)) {
@@ -225,6 +249,7 @@ inline size_t trimmed_len(const char *p, size_t n) {  // str::trim_end
 
 // One block of reads in the layout the C ABI takes (concatenated bases + n+1 offsets); ids and qualities are kept
 // only when POS/NEG filtering needs them (the reference drops them otherwise too, file_parser.rs:202-204,217-220).
+struct Segment;
 struct Batch {
     std::vector<uint8_t, HostAlloc<uint8_t>> seq;
     std::vector<uint64_t, HostAlloc<uint64_t>> off{0};
@@ -233,6 +258,11 @@ struct Batch {
     std::vector<char> qual;           // concatenated qualities when kept (bio does not require |qual| == |seq|)
     std::vector<uint64_t> qual_off{0};
     std::vector<uint8_t> has_qual;    // per read
+    // A batch assembled for POS/NEG filtering copies only what the device needs (the bases): ids and qualities stay in the
+    // parsed segments, which the batch holds until it has been written (append_ref).
+    bool external = false;
+    std::vector<std::string_view> ext_id, ext_qual;
+    std::vector<Segment *> held;
     size_t n() const { return off.size() - 1; }
     void clear() {
         seq.clear();
@@ -242,9 +272,16 @@ struct Batch {
         qual.clear();
         qual_off.assign(1, 0);
         has_qual.clear();
+        ext_id.clear();
+        ext_qual.clear();
+        external = false;
     }
-    std::string_view quality(size_t r) const { return std::string_view(qual.data() + qual_off[r], qual_off[r + 1] - qual_off[r]); }
-    std::string_view id(size_t r) const { return std::string_view(id_bytes.data() + id_off[r], id_off[r + 1] - id_off[r]); }
+    std::string_view quality(size_t r) const {
+        return external ? ext_qual[r] : std::string_view(qual.data() + qual_off[r], qual_off[r + 1] - qual_off[r]);
+    }
+    std::string_view id(size_t r) const {
+        return external ? ext_id[r] : std::string_view(id_bytes.data() + id_off[r], id_off[r + 1] - id_off[r]);
+    }
     // Record::id(): header[1..].trim_end() up to the first separator — any whitespace in bio's FASTA reader
     // (`splitn(2, char::is_whitespace)`), a blank only in its FASTQ reader (`splitn(2, ' ')`)
     void push_id(const char *h, size_t n, bool fastq) {
@@ -256,17 +293,65 @@ struct Batch {
     }
     // reads [r0, r1) of `o` appended to this batch
     void append(const Batch &o, size_t r0, size_t r1, bool keep) {
-        const uint64_t s0 = o.off[r0], s1 = o.off[r1], base = seq.size();
-        seq.insert(seq.end(), o.seq.begin() + s0, o.seq.begin() + s1);
-        for (size_t r = r0 + 1; r <= r1; ++r) off.push_back(base + (o.off[r] - s0));
-        if (!keep) return;
+        auto copy_seq = [&] {
+            const uint64_t s0 = o.off[r0], s1 = o.off[r1], base = seq.size();
+            seq.insert(seq.end(), o.seq.begin() + s0, o.seq.begin() + s1);
+            for (size_t r = r0 + 1; r <= r1; ++r) off.push_back(base + (o.off[r] - s0));
+        };
+        if (!keep) {
+            copy_seq();
+            return;
+        }
+        auto copy_qual = [&] {
+            const uint64_t q0 = o.qual_off[r0], q1 = o.qual_off[r1], qb = qual.size();
+            qual.insert(qual.end(), o.qual.begin() + q0, o.qual.begin() + q1);
+            for (size_t r = r0 + 1; r <= r1; ++r) qual_off.push_back(qb + (o.qual_off[r] - q0));
+        };
+        // sequences, qualities and ids are separate arrays: large pieces are copied side by side (the assembler thread was
+        // the slowest stage of the filtering pipeline: 10 GB of records through one core)
+        const bool big = r1 - r0 >= 4096;
+        std::thread ts, tq;
+        if (big) {
+            ts = std::thread(copy_seq);
+            tq = std::thread(copy_qual);
+        } else {
+            copy_seq();
+            copy_qual();
+        }
         const uint64_t i0 = o.id_off[r0], i1 = o.id_off[r1], ib = id_bytes.size();
         id_bytes.insert(id_bytes.end(), o.id_bytes.begin() + i0, o.id_bytes.begin() + i1);
         for (size_t r = r0 + 1; r <= r1; ++r) id_off.push_back(ib + (o.id_off[r] - i0));
-        const uint64_t q0 = o.qual_off[r0], q1 = o.qual_off[r1], qb = qual.size();
-        qual.insert(qual.end(), o.qual.begin() + q0, o.qual.begin() + q1);
-        for (size_t r = r0 + 1; r <= r1; ++r) qual_off.push_back(qb + (o.qual_off[r] - q0));
         has_qual.insert(has_qual.end(), o.has_qual.begin() + r0, o.has_qual.begin() + r1);
+        if (big) {
+            ts.join();
+            tq.join();
+        }
+    }
+    // reads [r0, r1) of `o`: bases copied, ids and qualities referenced (the caller keeps `o` alive, see `held`).  Large
+    // pieces are handled by four threads side by side: the arrays are sized first, every thread fills its range of reads.
+    void append_ref(const Batch &o, size_t r0, size_t r1) {
+        external = true;
+        const size_t n0 = n(), cnt = r1 - r0;
+        const uint64_t s0 = o.off[r0], s1 = o.off[r1], base = seq.size();
+        seq.resize(base + (s1 - s0));
+        off.resize(n0 + 1 + cnt);
+        ext_id.resize(n0 + cnt);
+        ext_qual.resize(n0 + cnt);
+        has_qual.resize(n0 + cnt);
+        auto part = [&](size_t a, size_t b) {  // reads [a, b) of the piece
+            memcpy(seq.data() + base + (o.off[r0 + a] - s0), o.seq.data() + o.off[r0 + a], o.off[r0 + b] - o.off[r0 + a]);
+            for (size_t i = a; i < b; ++i) {
+                off[n0 + 1 + i] = base + (o.off[r0 + i + 1] - s0);
+                ext_id[n0 + i] = o.id(r0 + i);
+                ext_qual[n0 + i] = o.quality(r0 + i);
+                has_qual[n0 + i] = o.has_qual[r0 + i];
+            }
+        };
+        const size_t T = cnt >= 16384 ? 4 : 1;
+        std::vector<std::thread> ts;
+        for (size_t t = 1; t < T; ++t) ts.emplace_back(part, cnt * t / T, cnt * (t + 1) / T);
+        part(0, cnt / T);
+        for (auto &t : ts) t.join();
     }
 };
 
@@ -374,6 +459,7 @@ struct RecordParser {
 // ---------------------------------------------------------------------------------------------------------------
 struct Segment {
     Batch b;
+    std::atomic<int> refs{0};             // the consumer + every batch that references the segment's ids / qualities
     std::vector<char> raw;                // plain chunks: the bytes of the file the records were parsed from
     uint64_t start_pos = 0, end_pos = 0;  // plain chunks: first record start, start of the record after the last one
     std::string err;                      // malformed input met after the records in b
@@ -576,8 +662,18 @@ struct ReadQueue {
     }
     void recycle(Segment *s) {
         std::lock_guard<std::mutex> lk(mu);
-        if (pool.size() < lookahead + 4) pool.push_back(s);
+        if (pool.size() < lookahead + 4 + (keep ? 48 : 0)) pool.push_back(s);  // (filtering: batches in flight hold their segments)
         else delete s;
+    }
+    // one holder less; the last one hands the segment back (a segment that ends in malformed input is not reused)
+    void release(Segment *s) {
+        if (--s->refs > 0) return;
+        if (!s->err.empty()) delete s;
+        else recycle(s);
+    }
+    void release_held(Batch &b) {
+        for (Segment *s : b.held) release(s);
+        b.held.clear();
     }
     void push(Task &t, Segment *s) {
         {
@@ -659,7 +755,8 @@ struct ReadQueue {
         return nullptr;
     }
     // Appends up to max_reads reads (and at most ~max_bytes bases); false when the input is exhausted.
-    bool fill(Batch &b, uint64_t max_reads, uint64_t max_bytes) {
+    // by_ref (needs keep): ids and qualities are referenced, not copied — the batch holds the segments (release_held).
+    bool fill(Batch &b, uint64_t max_reads, uint64_t max_bytes, bool by_ref = false) {
         if (!started) die("ReadQueue::start was not called");
         while (b.n() < max_reads && b.seq.size() < max_bytes) {
             if (!cur) {
@@ -668,6 +765,7 @@ struct ReadQueue {
                 ns_wait += now_ns() - t0;
                 cur_read = 0;
                 if (!cur) return false;
+                cur->refs = 1;  // this consumer
             }
             const size_t avail = cur->b.n() - cur_read;
             size_t take = (size_t)std::min<uint64_t>(avail, max_reads - b.n());
@@ -677,17 +775,23 @@ struct ReadQueue {
                 take = std::max<size_t>(t, 1);
             }
             const uint64_t t0 = now_ns();
-            if (take) b.append(cur->b, cur_read, cur_read + take, keep);
+            if (take && keep && by_ref) {
+                b.append_ref(cur->b, cur_read, cur_read + take);
+                if (b.held.empty() || b.held.back() != cur) {
+                    b.held.push_back(cur);
+                    ++cur->refs;
+                }
+            } else if (take) b.append(cur->b, cur_read, cur_read + take, keep);
             ns_append += now_ns() - t0;
             cur_read += take;
             if (cur_read == cur->b.n()) {
                 if (!cur->err.empty()) {
                     pending_error = cur->err;
-                    delete cur;
+                    release(cur);
                     cur = nullptr;
                     return false;
                 }
-                recycle(cur);
+                release(cur);
                 cur = nullptr;
             }
         }
@@ -905,10 +1009,13 @@ int cmd_query(int argc, char **argv) {
         die("cannot create POS_FILTERING in " + out);
     if (neg && (neg_fd = open((out + "/NEG_FILTERING." + ext).c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666)) < 0)
         die("cannot create NEG_FILTERING in " + out);
-    auto write_at = [](int fd, const std::string &buf, uint64_t at) {
-        for (size_t done = 0; done < buf.size();) {
-            ssize_t n = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(at + done));
-            if (n < 0) die(std::string("write error: ") + strerror(errno));
+    auto write_at = [](int fd, const char *buf, size_t len, uint64_t at) {
+        for (size_t done = 0; done < len;) {
+            ssize_t n = pwrite(fd, buf + done, len - done, (off_t)(at + done));
+            if (n < 0) {
+                fprintf(stderr, "phage_filter: write error: %s\n", strerror(errno));
+                _exit(101);  // (called from writer threads: see fail_from_thread)
+            }
             done += (size_t)n;
         }
     };
@@ -976,17 +1083,22 @@ int cmd_query(int argc, char **argv) {
         uint64_t batch_target = 1u << 20;
         if (const char *e = getenv("PFQ_CLI_BATCH_READS")) batch_target = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // (tests: several batches from a small input)
         const uint64_t batch_reads = std::max<uint64_t>(block, batch_target) / block * block;
-        // Batches are assembled on their own thread, ahead of the GPUs (one spare batch).  Batch k goes to whichever
-        // replica's thread asks next; outputs keep the input order: batch k's place in the two files is assigned when
-        // batch k-1's sizes are known, the bytes themselves are written side by side.
-        const size_t NB = n_dev + 1;
+        // Three stages, each on its own thread(s), batches in flight between them: (1) the assembler (above all the copy of
+        // the parsed records into batches of whole reference blocks), (2) one thread per replica: pfq_query_batch with hits,
+        // which are copied out of the library's buffers, (3) ONE output thread that takes the classified batches in input
+        // order, formats them with `threads` workers and writes every worker's part at its offset (pwrite, side by side) —
+        // while batch k is formatted and written, batch k + 1 is on the GPU and batch k + 2 is being assembled.
+        const size_t NB = n_dev + 3;
         std::vector<Batch> batches(NB);
-        std::vector<int> ready(NB, 0);          // 0 = free for the assembler, 1 = filled
-        std::vector<uint64_t> batch_seq(NB, 0);  // which batch a filled slot holds
+        std::vector<std::vector<uint64_t>> hit_off(NB);
+        std::vector<std::vector<uint32_t>> hit_leaves(NB);
+        std::vector<int> ready(NB, 0);          // 0 = free for the assembler, 1 = filled, 2 = classified
+        std::vector<uint64_t> batch_seq(NB, 0);  // which batch a slot holds
         std::mutex mu;
         std::condition_variable cv;
         long long last_seq = -1;                 // sequence number of the last batch, once the assembler knows it
-        uint64_t next_take = 0, next_write = 0;
+        uint64_t next_take = 0;
+        std::atomic<uint64_t> ns_fmt{0}, ns_write{0};
         std::thread parser([&] {
             bool more = true;
             for (uint64_t k = 0; more; ++k) {
@@ -995,8 +1107,9 @@ int cmd_query(int argc, char **argv) {
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return ready[slot] == 0; });
                 }
+                rq.release_held(batches[slot]);  // (written: its segments go back to the parsers)
                 batches[slot].clear();
-                more = rq.fill(batches[slot], batch_reads, 3ull << 30);
+                more = rq.fill(batches[slot], batch_reads, 3ull << 30, true);
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     ready[slot] = 1;
@@ -1006,9 +1119,7 @@ int cmd_query(int argc, char **argv) {
                 cv.notify_all();
             }
         });
-        const unsigned fmt_threads_per_dev = std::max(1u, threads / (unsigned)n_dev);
         auto device_loop = [&](size_t d) {
-            std::vector<std::string> pos_buf(fmt_threads_per_dev), neg_buf(fmt_threads_per_dev);
             while (true) {
                 uint64_t k;
                 size_t slot;
@@ -1021,118 +1132,304 @@ int cmd_query(int argc, char **argv) {
                 }
                 Batch &b = batches[slot];
                 const uint64_t n = b.n();
-                unsigned nw = 1;
-                std::vector<uint64_t> pos_at(2, 0), neg_at(2, 0);
-                pos_buf[0].clear();
-                neg_buf[0].clear();
-                uint64_t tq1 = ReadQueue::now_ns();
+                hit_off[slot].assign(n + 1, 0);
+                hit_leaves[slot].clear();
                 if (n) {
                     b.seq.resize(b.seq.size() + 16);
                     pfq_hits hits{};
                     const uint64_t tq0 = ReadQueue::now_ns();
                     if (pfq_query_batch(trees[d], b.seq.data(), b.off.data(), n, threshold, PFQ_WANT_HITS, &hits) != PFQ_OK)
                         fail_from_thread(pfq_last_error());
-                    tq1 = ReadQueue::now_ns();
-                    ns_gpu += tq1 - tq0;
+                    // (library-owned until the next call on this replica: the output thread works on copies)
+                    memcpy(hit_off[slot].data(), hits.offsets, (n + 1) * sizeof(uint64_t));
+                    hit_leaves[slot].assign(hits.leaves, hits.leaves + hits.offsets[n]);
+                    ns_gpu += ReadQueue::now_ns() - tq0;
                     n_total += n;
-                    // Blocks are independent (the ResultMap is cleared per block): worker w formats a contiguous range of
-                    // blocks into its own buffers.
-                    const uint64_t n_blocks = (n + block - 1) / block;
-                    nw = (unsigned)std::min<uint64_t>(fmt_threads_per_dev, n_blocks);
-                    auto format_range = [&](unsigned w) {
-                        std::string &pb = pos_buf[w], &nb = neg_buf[w];
-                        pb.clear();
-                        nb.clear();
-                        std::unordered_map<std::string_view, std::vector<uint32_t>> result_map;  // read id -> leaves (result_map.rs:20-22)
-                        for (uint64_t blk = n_blocks * w / nw; blk < n_blocks * (w + 1) / nw; ++blk) {
-                            const uint64_t b0 = blk * block, b1 = std::min(n, b0 + block);
-                            result_map.clear();
-                            for (uint64_t r = b0; r < b1; ++r) {
-                                if (hits.offsets[r] == hits.offsets[r + 1]) continue;
-                                std::vector<uint32_t> &v = result_map[b.id(r)];
-                                v.insert(v.end(), hits.leaves + hits.offsets[r], hits.leaves + hits.offsets[r + 1]);
-                            }
-                            for (auto &kv : result_map) {  // a set of genomes per id; printed in leaf order
-                                std::sort(kv.second.begin(), kv.second.end());
-                                kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
-                            }
-                            for (uint64_t r = b0; r < b1; ++r) {
-                                auto it = result_map.empty() ? result_map.end() : result_map.find(b.id(r));
-                                const bool mapped = it != result_map.end();  // read_mapped
-                                if (mapped ? !pos : !neg) continue;
-                                std::string &line = mapped ? pb : nb;
-                                line += b.has_qual[r] ? '@' : '>';  // write_record (main.rs:394-404)
-                                line.append(b.id(r));
-                                if (mapped) {                        // get_ext_id: "{id} |{g1,g2}" (set order unspecified in the reference)
-                                    line += " |";
-                                    bool first = true;
-                                    for (uint32_t leaf : it->second) {
-                                        if (!first) line += ',';
-                                        line += leaf_names[leaf];
-                                        first = false;
-                                    }
-                                }
-                                line += '\n';
-                                const size_t s0 = line.size();
-                                line.append((const char *)b.seq.data() + b.off[r], b.off[r + 1] - b.off[r]);
-                                for (size_t c = s0; c < line.size(); ++c) line[c] = (char)toupper((unsigned char)line[c]);  // main.rs:347-349
-                                line += '\n';
-                                if (b.has_qual[r]) {
-                                    line += "+\n";
-                                    line.append(b.quality(r));
-                                    line += '\n';
-                                }
-                            }
-                        }
-                    };
-                    std::vector<std::thread> fmt_threads;
-                    for (unsigned w = 1; w < nw; ++w) fmt_threads.emplace_back(format_range, w);
-                    format_range(0);
-                    for (auto &t : fmt_threads) t.join();
                 }
-                {   // my turn: the batches before this one have their places
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return next_write == k; });
-                    pos_at.assign(nw + 1, pos_size);
-                    neg_at.assign(nw + 1, neg_size);
-                    for (unsigned x = 0; x < nw; ++x) {
-                        pos_at[x + 1] = pos_at[x] + pos_buf[x].size();
-                        neg_at[x + 1] = neg_at[x] + neg_buf[x].size();
-                    }
-                    pos_size = pos_at[nw];
-                    neg_size = neg_at[nw];
-                    ++next_write;
-                }
-                cv.notify_all();
-                {   // the bytes: every formatter's part at its offset
-                    std::vector<std::thread> wr;
-                    auto write_part = [&](unsigned w) {
-                        if (pos_fd >= 0) write_at(pos_fd, pos_buf[w], pos_at[w]);
-                        if (neg_fd >= 0) write_at(neg_fd, neg_buf[w], neg_at[w]);
-                    };
-                    for (unsigned w = 1; w < nw; ++w) wr.emplace_back(write_part, w);
-                    write_part(0);
-                    for (auto &t : wr) t.join();
-                }
-                ns_out += ReadQueue::now_ns() - tq1;
                 {
                     std::lock_guard<std::mutex> lk(mu);
-                    ready[slot] = 0;
+                    ready[slot] = 2;
                 }
                 cv.notify_all();
             }
         };
+        // Output buffers of the formatters: grown with realloc (no zero fill), kept from batch to batch.
+        struct OutBuf {
+            char *p = nullptr;
+            size_t n = 0, cap = 0;
+            ~OutBuf() { free(p); }
+            char *room(size_t want) {
+                if (n + want > cap) {
+                    cap = std::max(n + want, cap + cap / 2 + (1u << 20));
+                    p = (char *)realloc(p, cap);
+                    if (!p) die("out of memory (output buffer)");
+                }
+                return p + n;
+            }
+            void put(const char *src, size_t len) {
+                memcpy(room(len), src, len);
+                n += len;
+            }
+            void put(char c) {
+                *room(1) = c;
+                ++n;
+            }
+        };
+        const unsigned fmt_workers = std::max(1u, threads);
+        // two sets of output buffers: while the writer thread puts set s into the files, the formatters fill the other one
+        std::vector<OutBuf> pos_sets[2] = {std::vector<OutBuf>(fmt_workers), std::vector<OutBuf>(fmt_workers)};
+        std::vector<OutBuf> neg_sets[2] = {std::vector<OutBuf>(fmt_workers), std::vector<OutBuf>(fmt_workers)};
+        struct WriteJob {
+            int state = 0;  // 0 free, 1 to be written
+            unsigned nw = 0;
+            std::vector<uint64_t> pos_at, neg_at;
+        } jobs[2];
+        bool writer_done = false;
+        std::thread writer([&] {
+            for (uint64_t j = 0;; ++j) {
+                WriteJob &job = jobs[j & 1];
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return job.state == 1 || writer_done; });
+                    if (job.state != 1) return;
+                }
+                const uint64_t t1 = ReadQueue::now_ns();
+                std::vector<OutBuf> &pb = pos_sets[j & 1], &nb = neg_sets[j & 1];
+                std::vector<std::thread> ts;
+                auto write_part = [&](unsigned w) {
+                    if (pos_fd >= 0) write_at(pos_fd, pb[w].p, pb[w].n, job.pos_at[w]);
+                    if (neg_fd >= 0) write_at(neg_fd, nb[w].p, nb[w].n, job.neg_at[w]);
+                };
+                for (unsigned w = 1; w < job.nw; ++w) ts.emplace_back(write_part, w);
+                write_part(0);
+                for (auto &t : ts) t.join();
+                ns_write += ReadQueue::now_ns() - t1;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    job.state = 0;
+                }
+                cv.notify_all();
+            }
+        });
+        std::thread output([&] {
+            // ResultMap of one block (result_map.rs:20-45) without allocations: an open-addressing table over the ids of the
+            // reads that hit.  An id that hits twice in a block (the same read id in two records) merges its genomes.
+            // Two phases per batch: (1) workers take whole blocks: table of the block's hit ids, then for EVERY read of the
+            // block its group (read_mapped: the id is in the block's map) — all hashing happens here; (2) workers take equal
+            // ranges of reads and only format (a block of 100 000 reads is formatted by several workers).
+            struct Group {
+                std::string_view id;
+                uint64_t first_read;          // the (first) read with this id that hit
+                int32_t merged;               // index into the block's merged sets once a second read with the id has hit
+            };
+            std::vector<Group> groups;                            // [hit reads of the batch], a slice per block
+            std::vector<uint32_t> table;                          // open-addressing tables of all blocks, a slice (power of two) per block
+            std::vector<uint64_t> grp0, tab0;                     // [blocks + 1] first group / first table slot of every block
+            std::vector<int32_t> grp_of;                          // [reads] group of the read within its block, -1: not mapped
+            std::vector<std::vector<std::vector<uint32_t>>> merged_of;  // [blocks] merged genome sets (ids that hit more than once)
+            auto hash_id = [](std::string_view v) {
+                uint64_t h = 0x9E3779B97F4A7C15ull ^ v.size();
+                size_t i = 0;
+                for (; i + 8 <= v.size(); i += 8) {
+                    uint64_t x;
+                    memcpy(&x, v.data() + i, 8);
+                    h = (h ^ x) * 0xff51afd7ed558ccdull;
+                    h ^= h >> 32;
+                }
+                uint64_t x = 0;
+                if (i < v.size()) memcpy(&x, v.data() + i, v.size() - i);
+                h = (h ^ x) * 0xc4ceb9fe1a85ec53ull;
+                return h ^ (h >> 29);
+            };
+            auto run_workers = [&](unsigned nw, const std::function<void(unsigned)> &fn) {
+                std::vector<std::thread> ts;
+                for (unsigned w = 1; w < nw; ++w) ts.emplace_back(fn, w);
+                fn(0);
+                for (auto &t : ts) t.join();
+            };
+            for (uint64_t k = 0;; ++k) {
+                const size_t slot = (size_t)(k % NB);
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return (ready[slot] == 2 && batch_seq[slot] == k) || (last_seq >= 0 && (long long)k > last_seq); });
+                    if (last_seq >= 0 && (long long)k > last_seq) return;
+                }
+                const Batch &b = batches[slot];
+                const uint64_t n = b.n();
+                const uint64_t *h_off = hit_off[slot].data();
+                const uint32_t *h_leaves = hit_leaves[slot].data();
+                {   // the buffer set of this batch must have been written
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return jobs[k & 1].state == 0; });
+                }
+                std::vector<OutBuf> &pos_buf = pos_sets[k & 1], &neg_buf = neg_sets[k & 1];
+                const uint64_t t0 = ReadQueue::now_ns();
+                const uint64_t n_blocks = n ? (n + block - 1) / block : 0;
+                // ---- phase 1: the blocks' maps
+                grp0.assign(n_blocks + 1, 0);
+                tab0.assign(n_blocks + 1, 0);
+                for (uint64_t blk = 0; blk < n_blocks; ++blk) {
+                    const uint64_t b0 = blk * block, b1 = std::min(n, b0 + block);
+                    uint64_t n_hit = 0;
+                    for (uint64_t r = b0; r < b1; ++r) n_hit += h_off[r] != h_off[r + 1];
+                    uint64_t want = 0;
+                    if (n_hit) {
+                        want = 16;
+                        while (want < 2 * n_hit) want <<= 1;
+                    }
+                    grp0[blk + 1] = grp0[blk] + n_hit;
+                    tab0[blk + 1] = tab0[blk] + want;
+                }
+                if (groups.size() < grp0[n_blocks]) groups.resize(grp0[n_blocks]);
+                table.assign(tab0[n_blocks], 0);
+                if (grp_of.size() < n) grp_of.resize(n);
+                merged_of.resize(std::max<size_t>(merged_of.size(), n_blocks));
+                const unsigned nw1 = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(fmt_workers, n_blocks));
+                run_workers(nw1, [&](unsigned w) {
+                    for (uint64_t blk = n_blocks * w / nw1; blk < n_blocks * (w + 1) / nw1; ++blk) {
+                        const uint64_t b0 = blk * block, b1 = std::min(n, b0 + block);
+                        Group *grp = groups.data() + grp0[blk];
+                        uint32_t *tab = table.data() + tab0[blk];
+                        const size_t mask = (size_t)(tab0[blk + 1] - tab0[blk]) - 1;   // (no table: the block has no hit)
+                        const bool any = tab0[blk + 1] != tab0[blk];
+                        auto &merged = merged_of[blk];
+                        merged.clear();
+                        uint32_t n_grp = 0;
+                        auto find = [&](std::string_view id, bool insert, uint64_t r) -> int32_t {
+                            for (size_t i = (size_t)hash_id(id) & mask;; i = (i + 1) & mask) {
+                                const uint32_t g = tab[i];
+                                if (!g) {
+                                    if (!insert) return -1;
+                                    grp[n_grp] = Group{id, r, -1};
+                                    tab[i] = ++n_grp;
+                                    return (int32_t)n_grp - 1;
+                                }
+                                if (grp[g - 1].id == id) return (int32_t)g - 1;
+                            }
+                        };
+                        if (any)
+                            for (uint64_t r = b0; r < b1; ++r) {
+                                if (h_off[r] == h_off[r + 1]) continue;
+                                const int32_t g = find(b.id(r), true, r);
+                                grp_of[r] = g;
+                                Group &gr = grp[g];
+                                if (gr.first_read == r) continue;        // new id
+                                if (gr.merged < 0) {                      // second read with this id: the sets merge
+                                    gr.merged = (int32_t)merged.size();
+                                    merged.emplace_back(h_leaves + h_off[gr.first_read], h_leaves + h_off[gr.first_read + 1]);
+                                }
+                                merged[gr.merged].insert(merged[gr.merged].end(), h_leaves + h_off[r], h_leaves + h_off[r + 1]);
+                            }
+                        for (auto &v : merged) {  // a set of genomes per id; printed in leaf order
+                            std::sort(v.begin(), v.end());
+                            v.erase(std::unique(v.begin(), v.end()), v.end());
+                        }
+                        for (uint64_t r = b0; r < b1; ++r)   // read_mapped: the id is in the block's map (also for reads that did not hit themselves)
+                            if (h_off[r] == h_off[r + 1]) grp_of[r] = any ? find(b.id(r), false, 0) : -1;
+                    }
+                });
+                // ---- phase 2: the records
+                const unsigned nw = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(fmt_workers, (n + 4095) / 4096));
+                run_workers(nw, [&](unsigned w) {
+                    OutBuf &pb = pos_buf[w], &nb = neg_buf[w];
+                    pb.n = nb.n = 0;
+                    for (uint64_t r = n * w / nw; r < n * (w + 1) / nw; ++r) {
+                        const int32_t g = grp_of[r];
+                        const bool mapped = g >= 0;
+                        if (mapped ? !pos : !neg) continue;
+                        OutBuf &line = mapped ? pb : nb;
+                        const std::string_view id = b.id(r);
+                        const uint64_t len = b.off[r + 1] - b.off[r];
+                        const bool fq = b.has_qual[r] != 0;
+                        {   // write_record (main.rs:394-404): '@' / '>' + id
+                            char *dst = line.room(id.size() + 3);
+                            dst[0] = fq ? '@' : '>';
+                            memcpy(dst + 1, id.data(), id.size());
+                            line.n += id.size() + 1;
+                        }
+                        if (mapped) {                              // get_ext_id: "{id} |{g1,g2}" (set order unspecified in the reference)
+                            line.put(" |", 2);
+                            const uint64_t blk = r / block;
+                            const Group &gr = groups[grp0[blk] + (uint64_t)g];
+                            const uint32_t *l0, *l1;
+                            if (gr.merged >= 0) {
+                                l0 = merged_of[blk][gr.merged].data();
+                                l1 = l0 + merged_of[blk][gr.merged].size();
+                            } else {
+                                l0 = h_leaves + h_off[gr.first_read];   // (ascending within a read, no duplicates)
+                                l1 = h_leaves + h_off[gr.first_read + 1];
+                            }
+                            for (const uint32_t *l = l0; l < l1; ++l) {
+                                if (l != l0) line.put(',');
+                                line.put(leaf_names[*l].data(), leaf_names[*l].size());
+                            }
+                        }
+                        const std::string_view q = fq ? b.quality(r) : std::string_view();
+                        char *dst = line.room(len + q.size() + 5);
+                        *dst++ = '\n';
+                        copy_upper(dst, b.seq.data() + b.off[r], len);   // the sequence, upper-cased (main.rs:347-349)
+                        dst += len;
+                        *dst++ = '\n';
+                        size_t wrote = len + 2;
+                        if (fq) {
+                            dst[0] = '+';
+                            dst[1] = '\n';
+                            memcpy(dst + 2, q.data(), q.size());
+                            dst[2 + q.size()] = '\n';
+                            wrote += q.size() + 3;
+                        }
+                        line.n += wrote;
+                    }
+                });
+                for (unsigned w = nw; w < fmt_workers; ++w) pos_buf[w].n = neg_buf[w].n = 0;
+                const uint64_t t1 = ReadQueue::now_ns();
+                ns_fmt += t1 - t0;
+                // the bytes: batches come in input order, so a part's place is the sum of what lies before it
+                std::vector<uint64_t> pos_at(nw + 1, pos_size), neg_at(nw + 1, neg_size);
+                for (unsigned x = 0; x < nw; ++x) {
+                    pos_at[x + 1] = pos_at[x] + pos_buf[x].n;
+                    neg_at[x + 1] = neg_at[x] + neg_buf[x].n;
+                }
+                pos_size = pos_at[nw];
+                neg_size = neg_at[nw];
+                ns_out += ReadQueue::now_ns() - t0;
+                {   // the batch is free again (everything it holds is in the buffers); the writer takes over
+                    std::lock_guard<std::mutex> lk(mu);
+                    ready[slot] = 0;
+                    jobs[k & 1].nw = nw;
+                    jobs[k & 1].pos_at = pos_at;
+                    jobs[k & 1].neg_at = neg_at;
+                    jobs[k & 1].state = 1;
+                }
+                cv.notify_all();
+            }
+        });
         std::vector<std::thread> th;
         for (size_t d = 1; d < n_dev; ++d) th.emplace_back(device_loop, d);
         device_loop(0);
         for (auto &t : th) t.join();
         parser.join();
+        output.join();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            writer_done = true;
+        }
+        cv.notify_all();
+        writer.join();
+        for (Batch &bb : batches) rq.release_held(bb);
+        if (getenv("PFQ_INGEST_TIMING"))
+            fprintf(stderr, "output: format %.3f s, write %.3f s (%u workers; wall times of the formatter and the writer thread, which overlap)\n",
+                    ns_fmt.load() * 1e-9, ns_write.load() * 1e-9, fmt_workers);
     }
     if (getenv("PFQ_INGEST_TIMING")) {
         const double wall = (ReadQueue::now_ns() - t_loop0) * 1e-9;
         fprintf(stderr, "query loop: %llu reads in %.3f s = %.2f M reads/s on %zu device(s) (pfq_query_batch %.3f s, output %.3f s)\n",
                 (unsigned long long)n_total.load(), wall, n_total.load() / wall * 1e-6, n_dev, ns_gpu.load() * 1e-9, ns_out.load() * 1e-9);
         rq.report_timing();
+        struct rusage ru;
+        if (getrusage(RUSAGE_SELF, &ru) == 0)
+            fprintf(stderr, "cpu: user %.2f s + system %.2f s so far (all threads) for %.2f s of query loop\n",
+                    ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6, ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6, wall);
     }
     if (pos_fd >= 0) close(pos_fd);
     if (neg_fd >= 0) close(neg_fd);

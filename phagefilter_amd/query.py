@@ -217,6 +217,17 @@ class BloomTree:
         _ffi.check(_ffi.lib().pfq_query_batch_device(self._h, d_seq, d_off, n_reads, total_bytes, threshold, 0,
                                                      stream, None))
 
+    def query_device_hits(self, d_seq: int, d_off: int, n_reads: int, total_bytes: int, threshold: float, stream: int = 0):
+        """The same block with PFQ_WANT_HITS: synchronous, returns the CSR (offsets, leaves) as views of the library's buffers
+        (valid until the next call on this tree)."""
+        hits = _ffi.Hits()
+        _ffi.check(_ffi.lib().pfq_query_batch_device(self._h, d_seq, d_off, n_reads, total_bytes, threshold, _ffi.WANT_HITS,
+                                                     stream, C.byref(hits)))
+        offs = np.ctypeslib.as_array(hits.offsets, shape=(n_reads + 1,)) if n_reads else np.zeros(1, dtype=np.uint64)
+        total = int(offs[-1])
+        leaves = np.ctypeslib.as_array(hits.leaves, shape=(total,)) if total else np.zeros(0, dtype=np.uint32)
+        return offs, leaves
+
     def export_counts(self, d_dst: int, stream: int = 0) -> None:
         _ffi.check(_ffi.lib().pfq_leaf_counts_export(self._h, d_dst, stream))
 

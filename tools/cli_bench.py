@@ -100,10 +100,12 @@ def main():
         assert p.returncode == 0, p.stderr
         loop = [l for l in p.stderr.splitlines() if l.startswith("query loop")]
         ingest = [l for l in p.stderr.splitlines() if l.startswith("ingest:")]
+        outl = [l for l in p.stderr.splitlines() if l.startswith("output:")]
+        cpul = [l for l in p.stderr.splitlines() if l.startswith("cpu:")]
         csv = open(os.path.join(out, "CLASSIFICATION.csv")).read().splitlines()
         print(json.dumps({"run": label, "threads": threads, "reads": n_reads, "whole_process_s": round(wall, 3),
                           "whole_process_reads_per_s": round(n_reads / wall), "query_loop": loop[0] if loop else None,
-                          "ingest": ingest[0] if ingest else None, "classified": sum(int(l.split(",")[1]) for l in csv)}), flush=True)
+                          "ingest": ingest[0] if ingest else None, "output": outl[0] if outl else None, "cpu": cpul[0] if cpul else None, "classified": sum(int(l.split(",")[1]) for l in csv)}), flush=True)
 
     for t in [int(x) for x in a.threads.split(",")]:
         run("fastq counts-only", fq, a.reads, t)
