@@ -160,7 +160,18 @@ struct pfq_tree {
     uint64_t internal_counter = 0;     // names of internal nodes created by pfq_tree_insert
     size_t n_rows = 0, row_capacity = 0;  // filter rows in use / allocated in d_bits
     DevBuf<uint32_t> d_build;          // insert scratch: leaf row, union triple
-    DevBuf<unsigned long long> d_dist; // insert scratch: Hamming distances (left, right)
+    DevBuf<unsigned long long> d_dist; // insert scratch: per-block partial Hamming distances (left, right) of two levels
+    // pfq_tree_insert walks the tree on the device (k_greedy_insert): its shape is mirrored there and the host's left / right /
+    // root are brought up to date when they are next needed (finish_topology)
+    DevBuf<pfq::TopoNode> d_topo;
+    DevBuf<int> d_walk;                // [0] root, [1] error word, [2..3] the grid barrier's arrival count and generation
+    bool topo_on_device = false;       // d_topo / d_walk mirror the host's nodes
+    bool topo_pending = false;         // insertions ran since the host last read the shape back
+    DevBuf<uint8_t> d_gseq[4];         // genomes of the insertions in flight (ring)
+    hipEvent_t gseq_free[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t gseq_next = 0;
+    int greedy_blocks = 0;
+
     pfq::HashParams hp{};
     // ---- device: node-major filters
     DevBuf<uint64_t> d_bits;
@@ -178,7 +189,7 @@ struct pfq_tree {
     bool coarse_valid = false;
     uint32_t coarse_cols = 0, coarse_rw = 0, coarse_rw_log2 = 0;
     double coarse_fill = 0.0;        // mean share of set bits of the coarse columns' filters
-    DevBuf<uint32_t> d_Sc, d_cgrp, d_glists;
+    DevBuf<uint32_t> d_Sc, d_cgrp, d_glists, d_glong;
     DevBuf<unsigned int> d_gcur;
     uint32_t last_coarse_cols = 0, last_coarse_probes = 0, last_leaf_groups = 0;
     DevBuf<uint32_t> d_S, d_col_row, d_guard_off, d_guard_col;
@@ -442,7 +453,27 @@ uint32_t optimal_num_hashes_f32(uint64_t bits, uint32_t items) {  // bloom_filte
 }
 
 // Nodes in pre-order again (root = 0) after pfq_tree_insert appended some; parents, depths and the ⊇ flags follow.
+// The shape the insertions on the device left (k_greedy_insert): children of every node, the root.
+int sync_topology(pfq_tree &t) {
+    if (!t.topo_pending) return PFQ_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<pfq::TopoNode> h(t.nodes.size());
+    int st[2] = {-1, 0};
+    HIP_TRY(hipMemcpy(h.data(), t.d_topo.p, h.size() * sizeof(pfq::TopoNode), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st, t.d_walk.p, sizeof st, hipMemcpyDeviceToHost));
+    t.topo_pending = false;
+    if (st[1] == 1) return fail(PFQ_ERR_FORMAT, "Node with only one child encountered - should not happen. (bloom_tree.rs:209)");
+    if (st[1] != 0) return fail(PFQ_ERR_DEVICE, "the insertion kernel's grid barrier timed out");
+    for (size_t v = 0; v < h.size(); ++v) {
+        t.nodes[v].left = h[v].left;
+        t.nodes[v].right = h[v].right;
+    }
+    t.root = st[0];
+    return PFQ_OK;
+}
+
 int finish_topology(pfq_tree &t) {
+    PFQ_TRY(sync_topology(t));
     if (!t.topology_dirty) return PFQ_OK;
     std::vector<int32_t> order, new_of(t.nodes.size(), -1);
     if (t.root >= 0) {
@@ -468,6 +499,7 @@ int finish_topology(pfq_tree &t) {
     t.root = t.nodes.empty() ? -1 : 0;
     relink(t);
     t.topology_dirty = false;
+    t.topo_on_device = false;  // (the nodes were renumbered)
     PFQ_TRY(verify_supersets(t));
     return PFQ_OK;
 }
@@ -476,6 +508,7 @@ int finish_topology(pfq_tree &t) {
 int reserve_rows(pfq_tree &t, size_t rows) {
     if (rows <= t.row_capacity) return PFQ_OK;
     size_t cap = std::max<size_t>(rows, t.row_capacity + t.row_capacity / 2 + 2);
+    HIP_TRY(hipDeviceSynchronize());  // (insertions in flight on the tree's own streams still write the old rows)
     uint64_t *p = nullptr;
     HIP_TRY(hipMalloc(&p, cap * t.n_words * 8));
     if (t.n_rows) HIP_TRY(hipMemcpy(p, t.d_bits.p, t.n_rows * t.n_words * 8, hipMemcpyDeviceToDevice));
@@ -606,7 +639,7 @@ int build_coarse(pfq_tree &t, const CoarsePlan &plan) {
     }
     const uint64_t sc_words = ((uint64_t)t.n_words * 64 + 1) * rwc;
     DevBuf<uint32_t> d_rows;
-    if (!(soft_ensure(t.d_Sc, sc_words) && soft_ensure(t.d_cgrp, C) && soft_ensure(t.d_gcur, pfq::MAX_LEAF_GROUPS) && soft_ensure(d_rows, C)))
+    if (!(soft_ensure(t.d_Sc, sc_words) && soft_ensure(t.d_cgrp, C) && soft_ensure(t.d_gcur, 2 * pfq::MAX_LEAF_GROUPS) && soft_ensure(d_rows, C)))
         return PFQ_OK;  // (no room: flat frontier)
     HIP_TRY(hipMemcpy(d_rows.p, plan.rows.data(), C * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.d_cgrp.p, plan.cgrp.data(), C * 4, hipMemcpyHostToDevice));
@@ -908,6 +941,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                     // every read at most once per list + one partly used reservation of 32 per wave of the (two) coarse launches
                     list_cap = (uint32_t)((n_reads + 2 * 32ull * 4 * (uint64_t)blocks + 63) & ~31ull);
                     if (!soft_ensure(t.d_glists, (size_t)list_cap * leaf_groups)) two_level = false;
+                    if (two_level && counts_mode && !soft_ensure(t.d_glong, (size_t)list_cap * leaf_groups)) two_level = false;
                 }
                 t.last_leaf_groups = leaf_groups;
                 t.last_coarse_cols = t.last_coarse_probes = 0;
@@ -947,21 +981,43 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                     ca.n_probes = np;
                     t.last_coarse_cols = t.coarse_cols;
                     t.last_coarse_probes = np;
-                    HIP_TRY(hipMemsetAsync(t.d_gcur.p, 0, pfq::MAX_LEAF_GROUPS * sizeof(unsigned int), st));
+                    HIP_TRY(hipMemsetAsync(t.d_gcur.p, 0, 2 * pfq::MAX_LEAF_GROUPS * sizeof(unsigned int), st));  // lists' cursors, long reads' cursors
                     pfq::launch_coarse(ac, ca, counts_mode, blocks, st);
+                }
+                if (two_level) {
+                    // ONE launch for all leaf groups (blockIdx.y = the group: its matrix, columns and list follow from it); the
+                    // queues of reads of >= 256 k-mers (thresholds < 1) are per group as well, behind the groups' cursors
+                    a.S = t.d_S.p;
+                    a.col0 = 0;
+                    a.n_leaves = (uint32_t)std::min<size_t>(group_cols, nl);
+                    a.first_group = 0;
+                    a.read_list = t.d_glists.p;
+                    a.n_list = t.d_gcur.p;
+                    a.grid_groups = leaf_groups;
+                    a.total_leaves = (uint32_t)nl;
+                    a.list_cap = list_cap;
+                    if (counts_mode) {
+                        a.long_list = t.d_glong.p;
+                        a.n_long = t.d_gcur.p + pfq::MAX_LEAF_GROUPS;
+                    }
+                    pfq::launch_classify(a, defer, counts_mode, blocks_group, st);
+                    a.read_list = nullptr;
+                    a.n_list = nullptr;
+                    a.grid_groups = 0;
+                    if (counts_mode) {
+                        a.long_list = t.d_long.p;
+                        a.n_long = reinterpret_cast<unsigned int *>(t.d_cursors.p + 4);
+                    }
+                    return PFQ_OK;
                 }
                 for (uint32_t g = 0; g < leaf_groups; ++g) {
                     a.S = t.d_S.p + (uint64_t)g * t.group_stride;
                     a.col0 = g * group_cols;
                     a.n_leaves = (uint32_t)std::min<size_t>(group_cols, nl - (size_t)g * group_cols);
-                    a.first_group = !two_level && g == 0;
-                    a.read_list = two_level ? t.d_glists.p + (size_t)g * list_cap : nullptr;
-                    a.n_list = two_level ? t.d_gcur.p + g : nullptr;
-                    if ((g || two_level) && counts_mode) HIP_TRY(hipMemsetAsync(t.d_cursors.p + 4, 0, 8, st));  // the queue of long reads is per launch
-                    pfq::launch_classify(a, defer, counts_mode, two_level ? blocks_group : blocks, st);
+                    a.first_group = g == 0;
+                    if (g && counts_mode) HIP_TRY(hipMemsetAsync(t.d_cursors.p + 4, 0, 8, st));  // the queue of long reads is per launch
+                    pfq::launch_classify(a, defer, counts_mode, blocks, st);
                 }
-                a.read_list = nullptr;
-                a.n_list = nullptr;
                 return PFQ_OK;
             };
             hipEvent_t *ev = nullptr;
@@ -1761,20 +1817,49 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
     PFQ_TRY(sync_counts_to_nodes(t));
     t.layout_valid = false;
     PFQ_TRY(reserve_rows(t, t.n_rows + 2));
-    HIP_TRY(t.d_build.ensure(8));
-    HIP_TRY(t.d_dist.ensure(2 * pfq::INSERT_STEP_BLOCKS));
-    std::vector<unsigned long long> part(2 * pfq::INSERT_STEP_BLOCKS);
-    // the new leaf's filter
-    const uint32_t new_row = (uint32_t)t.n_rows++;
+    if (!t.greedy_blocks) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, t.device));
+        // every block must be resident (one per CU at most); blocks of 1024 threads, half as many as CUs: enough to stream the
+        // filters, few enough pollers at the barrier
+        int want = prop.multiProcessorCount / 2;
+        if (const char *e = getenv("PFQ_GREEDY_BLOCKS")) want = atoi(e);
+        t.greedy_blocks = std::max(1, std::min(std::min(pfq::GREEDY_MAX_BLOCKS, prop.multiProcessorCount), want));
+    }
+    // the device's copy of the shape (all of it once; afterwards the kernel keeps it current)
+    const size_t n_after = t.nodes.size() + 2;
+    if (!t.topo_on_device || t.d_topo.n < n_after) {
+        PFQ_TRY(sync_topology(t));
+        HIP_TRY(hipDeviceSynchronize());
+        const size_t cap = std::max<size_t>(n_after, 2 * t.d_topo.n + 1024);
+        HIP_TRY(t.d_topo.ensure(cap));
+        HIP_TRY(t.d_walk.ensure(4));
+        HIP_TRY(t.d_dist.ensure(4 * (size_t)pfq::GREEDY_MAX_BLOCKS));
+        std::vector<pfq::TopoNode> h(t.nodes.size());
+        for (size_t v = 0; v < h.size(); ++v) h[v] = pfq::TopoNode{t.nodes[v].left, t.nodes[v].right, t.nodes[v].filter, 0u};
+        if (!h.empty()) HIP_TRY(hipMemcpy(t.d_topo.p, h.data(), h.size() * sizeof(pfq::TopoNode), hipMemcpyHostToDevice));
+        const int st[4] = {t.root, 0, 0, 0};
+        HIP_TRY(hipMemcpy(t.d_walk.p, st, sizeof st, hipMemcpyHostToDevice));
+        t.topo_on_device = true;
+    }
+    // the new leaf's filter: the genome goes to one of four staging buffers (the copy of genome i + 1 does not wait for the
+    // kernels of genome i), its k-mers are inserted into a cleared row
+    const uint32_t new_row = (uint32_t)t.n_rows++, int_row = (uint32_t)t.n_rows++;  // (the internal node's row stays unused by the first leaf of a tree)
+    const uint32_t slot = t.gseq_next++ & 3u;
+    if (!t.copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&t.copy_stream, hipStreamNonBlocking));
+        for (auto &e : t.in_free) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (!t.gseq_free[slot]) HIP_TRY(hipEventCreateWithFlags(&t.gseq_free[slot], hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(t.gseq_free[slot]));   // the insertion that used this buffer four calls ago has read it
+    if (t.d_gseq[slot].n < len + 16) {
+        HIP_TRY(t.d_gseq[slot].ensure(std::max<size_t>(len + 16, 2 * t.d_gseq[slot].n)));
+    }
+    if (len) HIP_TRY(hipMemcpyAsync(t.d_gseq[slot].p, seq, len, hipMemcpyHostToDevice, t.copy_stream));
+    HIP_TRY(hipStreamSynchronize(t.copy_stream));  // (its own stream: does not wait for the kernels of the insertions before)
     HIP_TRY(hipMemsetAsync(t.d_bits.p + (uint64_t)new_row * t.n_words, 0, t.n_words * 8, nullptr));
-    HIP_TRY(t.d_seq.ensure(len + 16));
-    HIP_TRY(t.d_off.ensure(2));
-    const uint64_t goff[2] = {0, len};
-    if (len) HIP_TRY(hipMemcpy(t.d_seq.p, seq, len, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t.d_off.p, goff, 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t.d_build.p, &new_row, 4, hipMemcpyHostToDevice));
-    pfq::launch_insert(t.hp, t.d_seq.p, t.d_off.p, 1, t.d_build.p, t.d_bits.p, t.n_words, nullptr);
-    HIP_TRY(hipGetLastError());
+    pfq::launch_insert_one(t.hp, t.d_gseq[slot].p, len, new_row, t.d_bits.p, t.n_words, nullptr);
+    HIP_TRY(hipEventRecord(t.gseq_free[slot], nullptr));
     Node leaf;
     leaf.has_tax = true;
     leaf.tax_id = tax_id;
@@ -1784,57 +1869,33 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
     const int32_t nv = (int32_t)t.nodes.size();
     t.nodes.push_back(leaf);
     t.topology_dirty = true;
-    if (t.root < 0) {
-        t.root = nv;
-        return PFQ_OK;
-    }
-    int32_t cur = t.root, parent = -1;
-    bool went_right = false;
-    while (true) {
-        const Node &c = t.nodes[cur];
-        if (c.left >= 0 && c.right >= 0) {
-            pfq::launch_insert_step(t.d_bits.p, t.n_words, c.filter, new_row, t.nodes[c.left].filter, t.nodes[c.right].filter,
-                                    t.d_dist.p, nullptr);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpy(part.data(), t.d_dist.p, part.size() * 8, hipMemcpyDeviceToHost));
-            unsigned long long d[2] = {0, 0};
-            for (uint32_t b = 0; b < pfq::INSERT_STEP_BLOCKS; ++b) {
-                d[0] += part[2 * b];
-                d[1] += part[2 * b + 1];
-            }
-            parent = cur;
-            went_right = d[1] < d[0];  // `if right_distance < left_distance` (bloom_tree.rs:201): ties go left
-            cur = went_right ? c.right : c.left;
-        } else if (c.is_leaf()) {
-            std::string name;
-            if (internal_name) name = internal_name;
-            else {
-                do name = "Internal_Node_" + std::to_string(t.internal_counter++);
-                while (std::find(t.filter_paths.begin(), t.filter_paths.end(), name + ".bf") != t.filter_paths.end());
-            }
-            const uint32_t int_row = (uint32_t)t.n_rows++;
-            const uint32_t triple[3] = {int_row, c.filter, new_row};
-            HIP_TRY(hipMemcpy(t.d_build.p + 4, triple, 12, hipMemcpyHostToDevice));
-            pfq::launch_union(t.d_bits.p, t.n_words, t.d_build.p + 4, 1, nullptr);
-            HIP_TRY(hipGetLastError());
-            Node in;
-            in.has_tax = true;
-            in.tax_id = name;
-            in.bf_path = name + ".bf";
-            in.filter = int_row;
-            in.left = cur;   // the node already in the tree (bloom_tree.rs:241)
-            in.right = nv;   // the new leaf (:242)
-            t.filter_paths.push_back(in.bf_path);
-            const int32_t ni = (int32_t)t.nodes.size();
-            t.nodes.push_back(in);
-            if (parent < 0) t.root = ni;
-            else (went_right ? t.nodes[parent].right : t.nodes[parent].left) = ni;
-            break;
-        } else {
-            return fail(PFQ_ERR_FORMAT, "Node with only one child encountered - should not happen. (bloom_tree.rs:209)");
+    // BloomTree::insert (bloom_tree.rs:128-143): the first leaf is the root; every later one is placed by the greedy descent,
+    // which ends in a new internal node (left = the leaf it reached, right = the new leaf, filter = their union)
+    int32_t ni = -1;
+    if (nv > 0 || t.root >= 0) {
+        std::string name;
+        if (internal_name) name = internal_name;
+        else {
+            do name = "Internal_Node_" + std::to_string(t.internal_counter++);
+            while (std::find(t.filter_paths.begin(), t.filter_paths.end(), name + ".bf") != t.filter_paths.end());
         }
+        Node in;
+        in.has_tax = true;
+        in.tax_id = name;
+        in.bf_path = name + ".bf";
+        in.filter = int_row;
+        in.right = nv;   // the new leaf (:242); `left` = the leaf the walk reaches, known on the device (sync_topology)
+        t.filter_paths.push_back(in.bf_path);
+        ni = (int32_t)t.nodes.size();
+        t.nodes.push_back(in);
+    } else {
+        --t.n_rows;  // (no internal node: its row is not used)
     }
-    HIP_TRY(hipDeviceSynchronize());
+    if (ni < 0) t.root = nv;  // (the host's root is only a hint while insertions are pending; empty vs. not is what counts)
+    pfq::launch_greedy_insert(t.d_bits.p, t.n_words, t.d_topo.p, t.d_walk.p, reinterpret_cast<unsigned int *>(t.d_walk.p + 2), t.d_dist.p, nv,
+                              ni < 0 ? nv : ni, new_row, int_row, t.greedy_blocks, nullptr);
+    HIP_TRY(hipGetLastError());
+    t.topo_pending = true;
     return PFQ_OK;
 }
 
@@ -1986,6 +2047,9 @@ void pfq_tree_close(pfq_tree *tree) {
         (void)hipStreamDestroy(tree->copy_stream);
         for (auto e : tree->in_free) (void)hipEventDestroy(e);
     }
+    for (auto e : tree->gseq_free)
+        if (e) (void)hipEventDestroy(e);
+
     if (tree->h_pair_cursor) (void)hipHostFree(tree->h_pair_cursor);
     if (tree->hint_ev) (void)hipEventDestroy(tree->hint_ev);
     delete tree;

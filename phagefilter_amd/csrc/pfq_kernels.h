@@ -44,6 +44,11 @@ struct QueryArgs {
     // (k_coarse) listed for it — reads with a live ancestor of one of the group's leaves
     const uint32_t *read_list;   // reads of this launch (entries 0xffffffff: unused slots of a reservation), nullptr: all reads
     const unsigned int *n_list;  // slots of read_list in use
+    // ONE launch serves every leaf group of a two-level frontier: blockIdx.y = the group; S, col0, n_leaves, read_list, n_list
+    // (and long_list / n_long) of the group follow from these (the host passes group 0's pointers)
+    uint32_t grid_groups;        // leaf groups of the launch (0: the launch is for the one group the fields above describe)
+    uint32_t total_leaves;       // leaves of the tree
+    uint32_t list_cap;           // slots per group in read_list and long_list
     uint32_t first_group;        // 1: this launch accounts for the per-read statistics (read bytes, all-hit reads)
     uint32_t ones_row;           // index of the all-ones row stored behind the last bit row of S
     uint32_t rw, rw_log2;        // row words (power of two <= 64)
@@ -295,6 +300,20 @@ void launch_prefix_open(const FinalizeArgs &a, const uint4 *meta, const uint32_t
 
 void launch_insert(const HashParams &hp, const uint8_t *d_genomes, const uint64_t *d_goff, uint32_t n_genomes,
                    const uint32_t *d_leaf_row, uint64_t *bits, uint64_t n_words, hipStream_t st);
+// one genome (device memory, len bytes) into filter row `row`
+void launch_insert_one(const HashParams &hp, const uint8_t *d_genome, uint64_t len, uint32_t row, uint64_t *bits, uint64_t n_words, hipStream_t st);
+// The greedy placement of one new leaf (BloomTree::insert, bloom_tree.rs:187-245) walked on the device in one launch; the tree's
+// shape is mirrored in device memory: a TopoNode per node, state[0] = the root's index (-1: empty), state[1] = error word
+// (1: a node with one child was met; 2: the grid's barrier timed out), bar = {arrival count, generation} of the grid barrier,
+// partials = 2 x 2 x blocks u64.  `blocks` must not exceed the number of CUs (every block has to be resident).
+struct TopoNode {
+    int32_t left, right;   // node indices, -1: none
+    uint32_t row;          // filter row
+    uint32_t pad_;
+};
+constexpr int GREEDY_MAX_BLOCKS = 256;  // (sizes the partial sums; the launch uses fewer: see pfq_tree_insert)
+void launch_greedy_insert(uint64_t *bits, uint64_t n_words, TopoNode *topo, int *state, unsigned int *bar, unsigned long long *partials,
+                          int leaf_node, int internal_node, uint32_t new_row, uint32_t int_row, int blocks, hipStream_t st);
 // dst[i] = a[i] | b[i] over rows given as triples (dst,a,b); b == 0xffffffff: copy a.
 void launch_union(uint64_t *bits, uint64_t n_words, const uint32_t *d_triples, uint32_t n_triples, hipStream_t st);
 // bits[cur] |= bits[new]; per-block partial Hamming distances: sum_b d_out[2b] = hamming(bits[left], bits[new]),

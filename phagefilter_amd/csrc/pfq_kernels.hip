@@ -621,6 +621,18 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
     __shared__ DenseLds<(DEFER && !LONG) || COUNTS> dlds;
     fill_complement(lds.comp);
     __syncthreads();
+    if ((LIST || LONG) && a.grid_groups) {  // (block-uniform) one launch for all leaf groups of a two-level frontier: mine is blockIdx.y
+        const uint32_t g = blockIdx.y;
+        a.S = a.S_all + (uint64_t)g * a.group_stride;
+        a.col0 = g << a.group_log2;
+        a.n_leaves = a.total_leaves - a.col0 < (1u << a.group_log2) ? a.total_leaves - a.col0 : (1u << a.group_log2);
+        a.read_list += (uint64_t)g * a.list_cap;
+        a.n_list += g;
+        if (COUNTS) {
+            a.long_list += (uint64_t)g * a.list_cap;
+            a.n_long += g;
+        }
+    }
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint64_t gw = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave, nw = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
     const uint32_t rw = a.rw;
@@ -895,7 +907,7 @@ static void launch_classify_l(const QueryArgs &a, bool defer, bool counts_mode, 
     }
 }
 void launch_classify(const QueryArgs &a, bool defer, bool counts_mode, int blocks, hipStream_t st) {
-    dim3 g(blocks), b(256);
+    dim3 g(blocks, a.grid_groups ? a.grid_groups : 1u), b(256);
     if (a.read_list) launch_classify_l<true>(a, defer, counts_mode, g, b, st);
     else launch_classify_l<false>(a, defer, counts_mode, g, b, st);
 }
@@ -2629,14 +2641,15 @@ void launch_finalize(const FinalizeArgs &a, hipStream_t st) {
 // Leaf filters: insert every canonical k-mer of genome g (what init_leaf_node does serially, bloom_tree.rs:154-168;
 // bits as ASMS::insert sets them, bloom_filter.rs:291-307).
 __global__ void __launch_bounds__(256) k_insert(HashParams hp, const uint8_t *genomes, const uint64_t *goff,
-                                                const uint32_t *leaf_row, uint64_t *bits, uint64_t n_words) {
+                                                const uint32_t *leaf_row, uint64_t *bits, uint64_t n_words, uint64_t len1, uint32_t row1) {
     __shared__ BlockLds lds;
     fill_complement(lds.comp);
     __syncthreads();
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, g = blockIdx.y;
-    const uint64_t o0 = goff[g], L = goff[g + 1] - o0;
+    // (goff == nullptr: ONE genome of len1 bytes into filter row row1 — no argument arrays to upload)
+    const uint64_t o0 = goff ? goff[g] : 0, L = goff ? goff[g + 1] - o0 : len1;
     const uint64_t n = (L >= hp.k) ? (L - hp.k + 1) : 0;
-    unsigned long long *row = reinterpret_cast<unsigned long long *>(bits + (uint64_t)leaf_row[g] * n_words);
+    unsigned long long *row = reinterpret_cast<unsigned long long *>(bits + (uint64_t)(goff ? leaf_row[g] : row1) * n_words);
     const uint64_t wid = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave, stride = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
     for (uint64_t base = wid * WIN_KMERS; base < n; base += stride * WIN_KMERS) {
         uint32_t cnt = (uint32_t)((n - base) < WIN_KMERS ? (n - base) : WIN_KMERS);
@@ -2654,7 +2667,151 @@ __global__ void __launch_bounds__(256) k_insert(HashParams hp, const uint8_t *ge
 void launch_insert(const HashParams &hp, const uint8_t *d_genomes, const uint64_t *d_goff, uint32_t n_genomes,
                    const uint32_t *d_leaf_row, uint64_t *bits, uint64_t n_words, hipStream_t st) {
     if (!n_genomes) return;
-    hipLaunchKernelGGL(k_insert, dim3(64, n_genomes), dim3(256), 0, st, hp, d_genomes, d_goff, d_leaf_row, bits, n_words);
+    hipLaunchKernelGGL(k_insert, dim3(64, n_genomes), dim3(256), 0, st, hp, d_genomes, d_goff, d_leaf_row, bits, n_words, 0ull, 0u);
+}
+void launch_insert_one(const HashParams &hp, const uint8_t *d_genome, uint64_t len, uint32_t row, uint64_t *bits, uint64_t n_words, hipStream_t st) {
+    hipLaunchKernelGGL(k_insert, dim3(64, 1), dim3(256), 0, st, hp, d_genome, (const uint64_t *)nullptr, (const uint32_t *)nullptr, bits, n_words, len, row);
+}
+
+// ---- BloomTree::insert's greedy descent (add_to_tree, bloom_tree.rs:187-245) in ONE launch -------------------------------
+// The whole walk happens on the device: at every two-child node the node absorbs the new leaf's filter (node_union) and the
+// walk continues into the child at smaller Hamming distance to the new leaf (right only if strictly closer, :201); the leaf it
+// reaches is replaced by a new internal node (left = the old leaf, right = the new leaf, filter = their union, :226-245).  The
+// topology lives in device memory (TopoNode per node, the root's index), so consecutive insertions need no host round trip:
+// the host only learns the shape when it next needs it.  The blocks of the grid meet at a barrier once per level (all of them
+// are resident: one per CU); every block then adds up the per-block partial distances itself, so all take the same turn.
+// A barrier that is not passed within a bounded number of polls sets the error word and every block leaves: the grid drains.
+__device__ __forceinline__ bool grid_barrier(unsigned int *count, unsigned int *gen, unsigned int &my_gen, int *err) {
+    __shared__ int s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int prev = atomicAdd(count, 1u);
+        if (prev == gridDim.x - 1u) {
+            atomicExch(count, 0u);
+            __threadfence();
+            atomicAdd(gen, 1u);
+        } else {
+            // (polled with a read-modify-write, which is performed at the memory side: a device-scope LOAD was seen to stay on a
+            // stale line of the poller's own XCD L2 — barriers timed out.  Few blocks, so that the pollers do not queue up.)
+            unsigned int polls = 0;
+            while (atomicAdd(gen, 0u) == my_gen) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++polls > (1u << 21)) {  // (seconds: some block of the grid never arrived)
+                    atomicExch(err, 2);
+                    break;
+                }
+            }
+        }
+        __threadfence();
+        s_ok = atomicAdd(err, 0) == 0;
+    }
+    ++my_gen;
+    __syncthreads();
+    return s_ok != 0;
+}
+__global__ void __launch_bounds__(1024) k_greedy_insert(uint64_t *bits, uint64_t n_words, TopoNode *topo, int *state /* root, err */,
+                                                        unsigned int *bar /* count, generation */, unsigned long long *partials,
+                                                        int leaf_node, int internal_node, uint32_t new_row, uint32_t int_row) {
+    __shared__ unsigned long long s_l[16], s_r[16];
+    __shared__ unsigned long long s_dl, s_dr;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, G = gridDim.x;
+    unsigned int my_gen = 0;
+    if (threadIdx.x == 0) s_dl = atomicAdd(&bar[1], 0u);
+    __syncthreads();
+    my_gen = (unsigned int)s_dl;   // (the generation the barrier word holds when this launch starts; nobody bumps it before all have read it:
+                                   //  the first bump needs every block's arrival)
+    const uint64_t *nw = bits + (uint64_t)new_row * n_words;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)G * blockDim.x;
+    int cur = state[0], parent = -1, side = 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) topo[leaf_node] = TopoNode{-1, -1, new_row, 0u};
+    if (cur < 0) {  // empty tree: the new leaf is the root
+        if (threadIdx.x == 0 && blockIdx.x == 0) state[0] = leaf_node;
+        return;
+    }
+    for (uint32_t level = 0;; ++level) {
+        const TopoNode c = topo[cur];
+        if (c.left >= 0 && c.right >= 0) {
+            uint64_t *crow = bits + (uint64_t)c.row * n_words;
+            const uint64_t *l = bits + (uint64_t)topo[c.left].row * n_words, *r = bits + (uint64_t)topo[c.right].row * n_words;
+            unsigned long long dl = 0, dr = 0;
+            for (uint64_t i = tid; i < n_words; i += nthreads) {
+                const uint64_t v = nw[i];
+                crow[i] |= v;                                            // node_union (bloom_tree.rs:194)
+                dl += (unsigned long long)__popcll(l[i] ^ v);          // distance (bloom_filter.rs:142-149)
+                dr += (unsigned long long)__popcll(r[i] ^ v);
+            }
+            for (int d = 32; d > 0; d >>= 1) {
+                dl += __shfl_down(dl, d);
+                dr += __shfl_down(dr, d);
+            }
+            if (lane == 0) {
+                s_l[wave] = dl;
+                s_r[wave] = dr;
+            }
+            __syncthreads();
+            unsigned long long *mine = partials + (uint64_t)(level & 1u) * 2u * G;
+            if (threadIdx.x == 0) {
+                unsigned long long a = 0, b = 0;
+                for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
+                    a += s_l[w];
+                    b += s_r[w];
+                }
+                mine[2u * blockIdx.x] = a;
+                mine[2u * blockIdx.x + 1u] = b;
+            }
+            if (!grid_barrier(&bar[0], &bar[1], my_gen, &state[1])) return;
+            // every block adds up all partials: the same sums, the same turn, everywhere
+            dl = dr = 0;
+            for (uint32_t b = threadIdx.x; b < G; b += blockDim.x) {
+                dl += mine[2u * b];
+                dr += mine[2u * b + 1u];
+            }
+            for (int d = 32; d > 0; d >>= 1) {
+                dl += __shfl_down(dl, d);
+                dr += __shfl_down(dr, d);
+            }
+            if (lane == 0) {
+                s_l[wave] = dl;
+                s_r[wave] = dr;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned long long a = 0, b = 0;
+                for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
+                    a += s_l[w];
+                    b += s_r[w];
+                }
+                s_dl = a;
+                s_dr = b;
+            }
+            __syncthreads();
+            parent = cur;
+            side = s_dr < s_dl ? 1 : 0;   // `if right_distance < left_distance` (bloom_tree.rs:201): ties go left
+            cur = side ? c.right : c.left;
+            __syncthreads();              // (s_dl / s_dr are rewritten at the next level)
+        } else if (c.left < 0 && c.right < 0) {
+            // the leaf is replaced by a new internal node over it and the new leaf (bloom_tree.rs:226-245)
+            uint64_t *irow = bits + (uint64_t)int_row * n_words;
+            const uint64_t *lrow = bits + (uint64_t)c.row * n_words;
+            for (uint64_t i = tid; i < n_words; i += nthreads) irow[i] = lrow[i] | nw[i];
+            if (threadIdx.x == 0 && blockIdx.x == 0) {
+                topo[internal_node] = TopoNode{cur, leaf_node, int_row, 0u};
+                if (parent < 0) state[0] = internal_node;
+                else if (side) topo[parent].right = internal_node;
+                else topo[parent].left = internal_node;
+            }
+            return;
+        } else {
+            if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(&state[1], 1);  // "Node with only one child encountered" (bloom_tree.rs:209)
+            return;
+        }
+    }
+}
+void launch_greedy_insert(uint64_t *bits, uint64_t n_words, TopoNode *topo, int *state, unsigned int *bar, unsigned long long *partials,
+                          int leaf_node, int internal_node, uint32_t new_row, uint32_t int_row, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_greedy_insert, dim3(blocks), dim3(1024), 0, st, bits, n_words, topo, state, bar, partials, leaf_node, internal_node,
+                       new_row, int_row);
 }
 
 // Internal filter = OR of its children (node_union, bloom_tree.rs:238-239 / bloom_filter.rs:275-278).

@@ -33,16 +33,21 @@ def main():
     # --false-pos-rate 0.001 --largest-genome 5000000 => 71 887 936 bits, 10 hashes (bloom_filter.rs:342-357)
     t0 = time.time()
     gt = BloomTree.new(21, 0.001, 5000000, 0x0123456789ABCDEF, 0xFEDCBA9876543210, expected_genomes=n_g)
+    marks = []
     for i in range(n_g):
         gt.insert(genomes[i].tobytes(), f"G{i:05d}")
-    info = gt.info()          # renumbers, verifies parent ⊇ child on every edge
+        if (i + 1) % 128 == 0:
+            marks.append(round(time.time() - t0, 3))
+    t_ins = time.time() - t0
+    info = gt.info()          # waits for the insertions, reads the shape back, renumbers, verifies parent ⊇ child on every edge
     torch.cuda.synchronize()
     wall = time.time() - t0
     depth = []
     counts = gt.get_leaf_counts()
     print(json.dumps({"genomes": n_g, "nodes": info.n_nodes, "leaves": info.n_leaves, "nbits": info.nbits,
                       "num_hashes": info.num_hashes, "superset_verified": info.superset_verified,
-                      "build_seconds": round(wall, 3), "genomes_per_s": round(n_g / wall, 1),
+                      "build_seconds": round(wall, 3), "genomes_per_s": round(n_g / wall, 1), "insert_calls_seconds": round(t_ins, 3),
+                      "seconds_after_every_128_insertions": marks,
                       "filter_bytes": info.n_nodes * ((info.nbits + 63) // 64) * 8}))
     gt.close()
 
