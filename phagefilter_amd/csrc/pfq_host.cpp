@@ -82,7 +82,7 @@ struct Knobs {
     long long record_gb = -1, tile_gb = -1, tile_entries = -1, slice_kb = -1;
     long long verify_blocks = -1, verify_chunk = -1, verify_sub = -1, verify_threads = -1, bin_blocks = -1, test_blocks = -1;
     long long tile = -1, tile_counts = -1, no_tail_batch = -1, bin_narrow = -1, bin_wide = -1, bin_debug = -1, block = -1;
-    long long coarse = -1, coarse_cols = -1, coarse_probes = -1, group_log2 = -1, screen_recs = -1;
+    long long coarse = -1, coarse_cols = -1, coarse_probes = -1, group_log2 = -1, screen_recs = -1, coarse_min_leaves = -1;
 };
 struct KnobName {
     const char *name;
@@ -103,7 +103,7 @@ const KnobName KNOBS[] = {
     {"PFQ_BLOCK", &Knobs::block},
     {"PFQ_COARSE", &Knobs::coarse},             {"PFQ_COARSE_COLS", &Knobs::coarse_cols},
     {"PFQ_COARSE_PROBES", &Knobs::coarse_probes}, {"PFQ_GROUP_LOG2", &Knobs::group_log2},
-    {"PFQ_SCREEN_RECS", &Knobs::screen_recs},
+    {"PFQ_SCREEN_RECS", &Knobs::screen_recs},   {"PFQ_COARSE_MIN_LEAVES", &Knobs::coarse_min_leaves},
 };
 bool set_knob(Knobs &k, const char *name, const char *value) {
     for (const KnobName &kn : KNOBS)
@@ -208,6 +208,7 @@ struct pfq_tree {
     DevBuf<uint8_t> d_T, d_failb;      // block mode: byte-per-index tables of the blocks of 8 leaves; failure bytes per (pair, leaf)
     bool tables_valid = false;         // d_T matches the current leaf set
     double cand_per_read = 1.0;        // candidate leaves per read seen by recent calls (related genomes: several): chooses block mode
+    bool have_cand_hint = false;       // cand_per_read describes this tree's workload (else a sample of the block is screened first)
     uint32_t last_block_mode = 0;
     DevBuf<uint32_t> d_round_k0, d_n_rounds, d_pair_kpos;  // thresholds < 1: LDS-tile passes with k-mer entries
     uint32_t last_tile_mode = 0, last_passes = 1;
@@ -698,7 +699,8 @@ int build_layout(pfq_tree &t) {
     // lists for the group when the tree has one (two-level frontier: groups of 1024 columns, one 128-byte line per row)
     t.coarse_valid = false;
     t.coarse_cols = 0;
-    bool want_coarse = nl > 2048 && t.knobs.coarse != 0;
+    const size_t coarse_min = t.knobs.coarse_min_leaves >= 1024 ? (size_t)t.knobs.coarse_min_leaves : 2048;
+    bool want_coarse = nl > coarse_min && t.knobs.coarse != 0;
     t.group_log2 = 11;
     CoarsePlan plan;
     if (want_coarse) {
@@ -754,6 +756,7 @@ int build_layout(pfq_tree &t) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     if (want_coarse) PFQ_TRY(build_coarse(t, plan));
+    t.have_cand_hint = false;
     t.tables_valid = false;
     t.layout_valid = true;
     return PFQ_OK;
@@ -788,6 +791,7 @@ bool ensure_bucket_scratch(pfq_tree &t, uint64_t n_reads, bool with_guards, uint
         if (t.hint_entry_cap) t.passes_hint = std::max<uint64_t>(1, (t.h_pair_cursor[1] + t.hint_entry_cap - 1) / t.hint_entry_cap);
         if (t.hint_counts) t.dirty_frac = (double)t.h_pair_cursor[2] / (double)std::max<unsigned long long>(1, t.h_pair_cursor[3] & 0xffffffffull);
         t.cand_per_read = (double)t.h_pair_cursor[4] / (double)t.hint_reads;
+        t.have_cand_hint = true;
         t.hint_reads = 0;
     }
     (void)hipGetLastError();  // hipEventQuery reports "not ready" through the error state
@@ -870,6 +874,55 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
     // sliced matrix afterwards, 1300 line gathers each, which pays while few leaves have guards: <= 5 % of them.)
     size_t guarded = 0;
     for (size_t c = 0; with_guards && c < nl; ++c) guarded += t.guard_off[c + 1] > t.guard_off[c];
+    // Candidate leaves per read decide between the pair pipeline and block mode.  Later calls take the figure of the call
+    // before; a call without that history (the first on a tree, the first after its layout changed) screens a sample of its
+    // OWN reads first — the frontier only, nothing is certified or counted — so that a workload of related genomes does not
+    // run its first block through the pair pipeline.  One small launch per column group and one read-back.
+    const bool block_eligible = bucketed && (thr_one || (thr_frac && kn.tile_counts != 0)) && recs_possible && n_tiles_block <= 560 &&
+                                n_blocks < (1u << 16) && (kn.tile < 0 || kn.tile != 0);
+    if (block_eligible && kn.block < 0 && !t.have_cand_hint && guarded * 20 <= nl) {
+        const uint64_t n_s = std::min<uint64_t>(n_reads, 16384);
+        HIP_TRY(hipMemsetAsync(t.d_stats.p, 0, pfq::ST_N * 8, st));
+        HIP_TRY(hipMemsetAsync(t.d_cursors.p, 0, 128, st));
+        pfq::QueryArgs sa{};
+        sa.hp = t.hp;
+        sa.seq = d_seq;
+        sa.off = d_off;
+        sa.n_reads = n_s;
+        sa.threshold = threshold;
+        sa.S_all = t.d_S.p;
+        sa.group_stride = t.group_stride;
+        sa.group_log2 = t.group_log2;
+        sa.ones_row = (uint32_t)(t.n_words * 64);
+        sa.rw = t.rw;
+        sa.rw_log2 = t.rw_log2;
+        sa.n_cols = t.n_cols;
+        sa.guard_off = t.d_guard_off.p;
+        sa.guard_col = t.d_guard_col.p;
+        sa.counts = t.d_counts.p;
+        sa.hit_cursor = t.d_cursors.p;
+        sa.stats = t.d_stats.p;
+        sa.screen_only = 1;
+        if (!(threshold >= 1.0f)) {
+            HIP_TRY(t.d_long.ensure(n_reads + 1));
+            sa.long_list = t.d_long.p;
+            sa.n_long = reinterpret_cast<unsigned int *>(t.d_cursors.p + 4);
+        }
+        for (uint32_t g = 0; g < leaf_groups; ++g) {
+            sa.S = t.d_S.p + (uint64_t)g * t.group_stride;
+            sa.col0 = g * group_cols;
+            sa.n_leaves = (uint32_t)std::min<size_t>(group_cols, nl - (size_t)g * group_cols);
+            sa.first_group = g == 0;
+            if (g && !(threshold >= 1.0f)) HIP_TRY(hipMemsetAsync(t.d_cursors.p + 4, 0, 8, st));
+            pfq::launch_classify(sa, false, !(threshold >= 1.0f), (int)std::min<uint64_t>((n_s + 3) / 4, CLASSIFY_MAX_BLOCKS), st);
+        }
+        HIP_TRY(hipGetLastError());
+        unsigned long long cand = 0;
+        HIP_TRY(hipMemcpyAsync(&cand, t.d_stats.p + pfq::ST_CANDIDATES, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        t.cand_per_read = (double)cand / (double)n_s;
+        t.have_cand_hint = true;
+    }
     // At thresholds below 1 block mode keeps the k-mer entries: buckets by (block, candidate mask), 8 miss bytes per k-mer.
     bool block_mode = bucketed && (thr_one || (thr_frac && kn.tile_counts != 0)) && recs_possible && n_tiles_block <= 560 && n_blocks < (1u << 16) &&
                       (kn.block >= 0 ? kn.block != 0 : (t.cand_per_read > 1.5 && guarded * 20 <= nl)) && (kn.tile < 0 || kn.tile != 0);
@@ -2421,7 +2474,7 @@ int pfq_set_option(pfq_tree *tree, const char *name, const char *value) {
     if (!tree || !name) return fail(PFQ_ERR_ARG, "null argument");
     if (!set_knob(tree->knobs, name, value)) return fail(PFQ_ERR_ARG, std::string("unknown option ") + name);
     // knobs of the device layout (column groups, coarse level): the layout is rebuilt before the next use
-    if (!strcmp(name, "PFQ_COARSE") || !strcmp(name, "PFQ_COARSE_COLS") || !strcmp(name, "PFQ_GROUP_LOG2")) {
+    if (!strcmp(name, "PFQ_COARSE") || !strcmp(name, "PFQ_COARSE_COLS") || !strcmp(name, "PFQ_GROUP_LOG2") || !strcmp(name, "PFQ_COARSE_MIN_LEAVES")) {
         if (tree->layout_valid) {
             PFQ_TRY(use_device(tree->device));
             PFQ_TRY(sync_counts_to_nodes(*tree));

@@ -75,6 +75,7 @@ struct QueryArgs {
     uint32_t batch_tails;        // theta == 1 with records: last windows of <= TAIL_KMERS k-mers are left to k_tail_records
     uint32_t block_pairs;        // 1 (DEFER, theta == 1, no guard columns): defer (read, block of 8 leaves | candidate mask << 24)
     uint32_t screen_recs;        // thresholds < 1: the dense counting screen writes the probe records of the k-mers it hashes
+    uint32_t screen_only;        // (launches without deferral) count the frontier's candidate leaves, certify nothing, count no read
     // thresholds < 1: every deferred pair owns ceil(n/64) u64 words of k-mer miss bits.  k_classify only accounts for
     // them (per bucket, and against the buffer's capacity through per-wave reservations); k_bucket_scatter places them.
     uint32_t *bucket_words;            // [n_leaves << sub_log2] miss words per bucket, or nullptr (threshold 1)

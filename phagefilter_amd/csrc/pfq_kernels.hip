@@ -749,6 +749,7 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
                 }
                 // no room left in the pair buffer: certify inline below (results stay exact)
             }
+            if (!DEFER && a.screen_only) continue;  // (a sample of the block is screened to see how many candidates a read has)
             for (uint32_t jb = 0; jb < (BLOCKS ? 8u : 1u); ++jb) {  // (BLOCKS: the candidates of the block one by one)
                 if (!((mask8 >> jb) & 1u)) continue;
                 const uint32_t cj = col + jb;
@@ -861,7 +862,7 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
     if (DEFER && pair_used < PAIR_CHUNK)
         for (uint32_t i = pair_used + lane; i < PAIR_CHUNK; i += 64) a.pairs[pair_base + i] = make_uint2(0xffffffffu, 0xffffffffu);
     // reads that pass every node (need == 0) count at every leaf (query.rs:143 reached through every path)
-    if (st_all)
+    if (st_all && !(!DEFER && a.screen_only))
         for (uint32_t c = lane; c < a.n_leaves; c += 64) atomicAdd(&a.counts[a.col0 + c], st_all);
     if (!a.first_group) st_all = 0;  // (statistics count a read once)
     for (int dd = 32; dd > 0; dd >>= 1) dense_bytes += __shfl_down(dense_bytes, dd);

@@ -117,7 +117,7 @@ def test_config3_geometry_thresholds_below_one_vs_oracle(gpu):
 
 def test_config3_geometry_families_of_8_vs_oracle(gpu):
     """128 families of 8 genomes 0.5 % apart at nbits 71 887 936: a read is a candidate for up to 8 leaves (block mode is what
-    the library turns to after its first call on such a workload; here it is also forced on the first)."""
+    the library turns to on such a workload, from the first call on)."""
     rng = np.random.default_rng(77)
     base = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (N_LEAVES // 8, GLEN))]
     genomes = np.repeat(base, 8, axis=0)
@@ -144,6 +144,7 @@ def test_config3_geometry_families_of_8_vs_oracle(gpu):
                 for key in opts:
                     gt.set_option(key, None)
             assert st.path == 1 and counts == want_counts and np.array_equal(hits, want_hits), (thr, name)
-            if name != "first-call":
-                assert st.tile_mode == 2, (thr, name)              # block mode: forced, then chosen from what the calls before saw
+            # block mode every time: the first call on the tree has no history and screens a sample of its own reads
+            # (several candidate leaves per read), the forced call, then the choice from what the call before saw
+            assert st.tile_mode == 2, (thr, name)
     gt.close()
