@@ -240,8 +240,13 @@ struct pfq_tree {
     // ---- outputs (library-owned)
     std::vector<std::string> out_tax;
     std::vector<const char *> out_tax_ptr;
-    std::vector<uint64_t> out_counts, hit_offsets;
-    std::vector<uint32_t> hit_leaves;
+    std::vector<uint64_t> out_counts;
+    // per-read hit lists of the last PFQ_WANT_HITS call: built on the device, copied into page-locked host memory
+    DevBuf<uint32_t> d_hit_cnt, d_hit_leaves;
+    DevBuf<unsigned long long> d_hit_sums, d_hit_off;
+    uint64_t *h_hit_off = nullptr;
+    uint32_t *h_hit_leaves = nullptr;
+    size_t h_hit_off_cap = 0, h_hit_leaves_cap = 0;
 };
 
 namespace {
@@ -1434,28 +1439,46 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
         HIP_TRY(hipMemcpy(cursors, t.d_cursors.p, 16, hipMemcpyDeviceToHost));
         if (n_reads) t.hits_per_read = std::max(t.hits_per_read, (double)cursors[0] / (double)n_reads);
         if (cursors[0] <= hit_cap) {
-            // CSR read -> leaves (ascending), all-hit reads expand to every leaf
-            std::vector<uint2> pairs((size_t)cursors[0]);
-            if (!pairs.empty()) HIP_TRY(hipMemcpy(pairs.data(), t.d_hit_pairs.p, pairs.size() * 8, hipMemcpyDeviceToHost));
-            std::vector<uint8_t> allhit((size_t)n_reads);
-            if (n_reads) HIP_TRY(hipMemcpy(allhit.data(), t.d_allhit.p, (size_t)n_reads, hipMemcpyDeviceToHost));
-            t.hit_offsets.assign((size_t)n_reads + 1, 0);
-            for (auto &p : pairs) ++t.hit_offsets[p.x + 1];
-            for (uint64_t r = 0; r < n_reads; ++r)
-                if (allhit[r]) t.hit_offsets[r + 1] = nl;
-            for (uint64_t r = 0; r < n_reads; ++r) t.hit_offsets[r + 1] += t.hit_offsets[r];
-            t.hit_leaves.assign((size_t)t.hit_offsets[n_reads], 0);
-            std::vector<uint64_t> fill(t.hit_offsets.begin(), t.hit_offsets.end() - 1);
-            for (auto &p : pairs) t.hit_leaves[fill[p.x]++] = p.y;
-            for (uint64_t r = 0; r < n_reads; ++r) {
-                if (allhit[r])
-                    for (uint32_t c = 0; c < nl; ++c) t.hit_leaves[t.hit_offsets[r] + c] = c;
-                else
-                    std::sort(t.hit_leaves.begin() + t.hit_offsets[r], t.hit_leaves.begin() + t.hit_offsets[r + 1]);
-            }
+            // CSR read -> leaves (ascending; reads that pass every node list every leaf), built on the device from the
+            // unordered hit pairs and copied into page-locked host buffers
+            auto host_room = [&](void **p, size_t &cap, size_t want) -> int {
+                if (want <= cap) return PFQ_OK;
+                if (*p) (void)hipHostFree(*p);
+                *p = nullptr;
+                cap = 0;
+                const size_t grown = want + want / 4 + 4096;
+                HIP_TRY(hipHostMalloc(p, grown, hipHostMallocDefault));
+                cap = grown;
+                return PFQ_OK;
+            };
+            PFQ_TRY(host_room((void **)&t.h_hit_off, t.h_hit_off_cap, ((size_t)n_reads + 1) * 8));
+            t.h_hit_off[0] = 0;
+            uint64_t total = 0;
+            if (n_reads) {
+                unsigned long long n_allhit = 0;
+                HIP_TRY(hipMemcpy(&n_allhit, t.d_stats.p + pfq::ST_ALLHIT, 8, hipMemcpyDeviceToHost));
+                HIP_TRY(t.d_hit_cnt.ensure(n_reads + 1));
+                HIP_TRY(t.d_hit_off.ensure(n_reads + 2));
+                HIP_TRY(t.d_hit_sums.ensure((n_reads + 4095) / 4096 + 2));
+                HIP_TRY(hipMemsetAsync(t.d_hit_cnt.p, 0, (n_reads + 1) * 4, st));
+                pfq::launch_hits_csr(t.d_hit_pairs.p, cursors[0], t.d_allhit.p, n_reads, (uint32_t)nl, n_allhit != 0, t.d_hit_cnt.p, t.d_hit_sums.p,
+                                     t.d_hit_off.p, st);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(t.h_hit_off, t.d_hit_off.p, (n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                total = t.h_hit_off[n_reads];
+                PFQ_TRY(host_room((void **)&t.h_hit_leaves, t.h_hit_leaves_cap, (size_t)total * 4 + 4));
+                if (total) {
+                    HIP_TRY(t.d_hit_leaves.ensure(total));
+                    pfq::launch_hits_fill(t.d_hit_pairs.p, cursors[0], t.d_allhit.p, n_reads, t.d_hit_off.p, t.d_hit_cnt.p, t.d_hit_leaves.p, st);
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipMemcpyAsync(t.h_hit_leaves, t.d_hit_leaves.p, total * 4, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                }
+            } else PFQ_TRY(host_room((void **)&t.h_hit_leaves, t.h_hit_leaves_cap, 4));
             hits->n_reads = n_reads;
-            hits->offsets = t.hit_offsets.data();
-            hits->leaves = t.hit_leaves.data();
+            hits->offsets = t.h_hit_off;
+            hits->leaves = t.h_hit_leaves;
             return PFQ_OK;
         }
         // hit buffer too small: restore the counters and run the block again with room for every hit
@@ -2102,6 +2125,8 @@ void pfq_tree_close(pfq_tree *tree) {
     }
     for (auto e : tree->gseq_free)
         if (e) (void)hipEventDestroy(e);
+    if (tree->h_hit_off) (void)hipHostFree(tree->h_hit_off);
+    if (tree->h_hit_leaves) (void)hipHostFree(tree->h_hit_leaves);
 
     if (tree->h_pair_cursor) (void)hipHostFree(tree->h_pair_cursor);
     if (tree->hint_ev) (void)hipEventDestroy(tree->hint_ev);

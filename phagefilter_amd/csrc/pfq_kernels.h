@@ -330,6 +330,13 @@ void launch_transpose(const uint64_t *bits, uint64_t n_words, const uint32_t *d_
 // dst[i] = a[i] + b[i], or a[i] - b[i] (u64 counters; the count reductions over replicas / ranks work on what a replica
 // counted since it was opened: counters - base)
 void launch_counts_op(unsigned long long *dst, const unsigned long long *a, const unsigned long long *b, uint32_t n, bool subtract, hipStream_t st);
+// PFQ_WANT_HITS: the CSR read -> leaves from the unordered (read, leaf) hit pairs, on the device.  launch_hits_csr: counts per
+// read (d_cnt, zeroed by the caller; reads flagged in d_allhit list every leaf) and their exclusive scan d_off[n_reads + 1];
+// launch_hits_fill: the leaves, ascending within a read.  d_sums: ceil(n_reads / 4096) + 1 words of scratch.
+void launch_hits_csr(const uint2 *d_pairs, uint64_t n_pairs, const uint8_t *d_allhit, uint64_t n_reads, uint32_t n_leaves, bool any_allhit,
+                     uint32_t *d_cnt, unsigned long long *d_sums, unsigned long long *d_off, hipStream_t st);
+void launch_hits_fill(const uint2 *d_pairs, uint64_t n_pairs, const uint8_t *d_allhit, uint64_t n_reads, const unsigned long long *d_off,
+                      uint32_t *d_cnt, uint32_t *d_leaves, hipStream_t st);
 void launch_debug_indices(const HashParams &hp, const uint8_t *d_seq, uint64_t len, uint64_t *d_out, hipStream_t st);
 void launch_synth_genomes(uint8_t *d_out, uint64_t n_genomes, uint64_t genome_len, uint64_t seed_base, hipStream_t st);
 void launch_synth_reads(uint8_t *d_out, uint64_t first, uint64_t n_reads, uint64_t read_len, const uint8_t *d_genomes,

@@ -2947,6 +2947,122 @@ void launch_row_popcount(const uint64_t *bits, uint64_t n_words, const uint32_t 
     if (n_rows) hipLaunchKernelGGL(k_row_popcount, dim3(n_rows), dim3(256), 0, st, bits, n_words, d_rows, d_out);
 }
 
+// ---- per-read hit lists (PFQ_WANT_HITS): CSR read -> leaves built on the device ----------------------------------------
+// The kernels append (read, leaf) hit pairs in whatever order their waves finish; the seam of query.rs:146-154 wants, per
+// read, its leaves.  Count per read, exclusive scan, scatter, sort each read's few leaves (reads that pass every node list
+// every leaf): all of it at device bandwidth instead of host loops over millions of reads.
+__global__ void __launch_bounds__(256) k_hit_count(const uint2 *pairs, uint64_t n_pairs, uint32_t *cnt) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += (uint64_t)gridDim.x * blockDim.x) atomicAdd(&cnt[pairs[i].x], 1u);
+}
+__global__ void __launch_bounds__(256) k_hit_allhit(const uint8_t *allhit, uint64_t n_reads, uint32_t *cnt, uint32_t n_leaves) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x)
+        if (allhit[r]) cnt[r] = n_leaves;
+}
+constexpr uint32_t SCAN_ITEMS = 4096;  // elements per block of 1024 threads
+__global__ void __launch_bounds__(1024) k_scan_sums(const uint32_t *cnt, uint64_t n, unsigned long long *sums) {
+    __shared__ unsigned long long s_w[16];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_ITEMS;
+    unsigned long long v = 0;
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint64_t i = base + threadIdx.x * 4u + j;
+        if (i < n) v += cnt[i];
+    }
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += s_w[w];
+        sums[blockIdx.x] = t;
+    }
+}
+__global__ void __launch_bounds__(1024) k_scan_top(unsigned long long *sums, uint32_t n_blocks) {  // one block: exclusive scan in place
+    __shared__ unsigned long long s_w[16];
+    __shared__ unsigned long long s_run;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 1024) {
+        const uint32_t i = b0 + threadIdx.x;
+        const unsigned long long x = i < n_blocks ? sums[i] : 0ull;
+        unsigned long long incl = x;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(incl, d);
+            if ((int)lane_id() >= d) incl += o;
+        }
+        if (lane_id() == 63) s_w[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned long long before = s_run;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += s_w[w];
+        if (i < n_blocks) sums[i] = before + incl - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_run = before + incl;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(1024) k_scan_apply(const uint32_t *cnt, uint64_t n, const unsigned long long *sums, unsigned long long *off) {
+    __shared__ unsigned long long s_w[16];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_ITEMS + threadIdx.x * 4u;
+    uint32_t c[4];
+    unsigned long long mine = 0;
+    for (uint32_t j = 0; j < 4; ++j) {
+        c[j] = base + j < n ? cnt[base + j] : 0u;
+        mine += c[j];
+    }
+    unsigned long long incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(incl, d);
+        if ((int)lane_id() >= d) incl += o;
+    }
+    if (lane_id() == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned long long run = sums[blockIdx.x] + incl - mine;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) run += s_w[w];
+    for (uint32_t j = 0; j < 4; ++j) {
+        if (base + j < n) off[base + j] = run;
+        run += c[j];
+        if (base + j + 1 == n) off[n] = run;  // the total
+    }
+}
+__global__ void __launch_bounds__(256) k_hit_scatter(const uint2 *pairs, uint64_t n_pairs, const unsigned long long *off, uint32_t *cnt, uint32_t *leaves) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 p = pairs[i];
+        leaves[off[p.x] + (atomicSub(&cnt[p.x], 1u) - 1u)] = p.y;  // (filled from the end: the order is fixed by the sort below)
+    }
+}
+__global__ void __launch_bounds__(256) k_hit_sort(const unsigned long long *off, uint32_t *leaves, const uint8_t *allhit, uint64_t n_reads) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long o0 = off[r], o1 = off[r + 1];
+        if (allhit[r]) {  // passes every node: every leaf, in order
+            for (unsigned long long i = o0; i < o1; ++i) leaves[i] = (uint32_t)(i - o0);
+            continue;
+        }
+        for (unsigned long long i = o0 + 1; i < o1; ++i) {  // ascending within a read (a handful of leaves: insertion sort)
+            const uint32_t v = leaves[i];
+            unsigned long long j = i;
+            while (j > o0 && leaves[j - 1] > v) {
+                leaves[j] = leaves[j - 1];
+                --j;
+            }
+            leaves[j] = v;
+        }
+    }
+}
+void launch_hits_csr(const uint2 *d_pairs, uint64_t n_pairs, const uint8_t *d_allhit, uint64_t n_reads, uint32_t n_leaves, bool any_allhit,
+                     uint32_t *d_cnt, unsigned long long *d_sums, unsigned long long *d_off, hipStream_t st) {
+    // d_cnt: [n_reads] zeroed by the caller; d_sums: [ceil(n_reads / SCAN_ITEMS) + 1]; d_off: [n_reads + 1]
+    const uint32_t n_blocks = (uint32_t)((n_reads + SCAN_ITEMS - 1) / SCAN_ITEMS);
+    if (n_pairs) hipLaunchKernelGGL(k_hit_count, dim3(2048), dim3(256), 0, st, d_pairs, n_pairs, d_cnt);
+    if (any_allhit) hipLaunchKernelGGL(k_hit_allhit, dim3(2048), dim3(256), 0, st, d_allhit, n_reads, d_cnt, n_leaves);
+    hipLaunchKernelGGL(k_scan_sums, dim3(n_blocks), dim3(1024), 0, st, d_cnt, n_reads, d_sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_sums, n_blocks);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_blocks), dim3(1024), 0, st, d_cnt, n_reads, d_sums, d_off);
+}
+void launch_hits_fill(const uint2 *d_pairs, uint64_t n_pairs, const uint8_t *d_allhit, uint64_t n_reads, const unsigned long long *d_off,
+                      uint32_t *d_cnt, uint32_t *d_leaves, hipStream_t st) {
+    if (n_pairs) hipLaunchKernelGGL(k_hit_scatter, dim3(2048), dim3(256), 0, st, d_pairs, n_pairs, d_off, d_cnt, d_leaves);
+    hipLaunchKernelGGL(k_hit_sort, dim3(4096), dim3(256), 0, st, d_off, d_leaves, d_allhit, n_reads);
+}
+
 // ---- test / bench helpers ----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_debug_indices(HashParams hp, const uint8_t *seq, uint64_t len, uint64_t *out) {
     __shared__ BlockLds lds;
