@@ -826,66 +826,129 @@ constexpr int PROF_EV = 7;  // start, classify, bucket, plan+bin, test, verify, 
 constexpr uint64_t BUCKET_MIN_READS = 1ull << 18;  // below this the bucketed pass cannot amortise warming the L2 slices
 constexpr uint64_t SLICE_TARGET_BYTES = 2560ull << 10;
 
-int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint64_t n_reads, uint64_t total_bytes,
-                 float threshold, uint32_t flags, hipStream_t st, pfq_hits *hits) {
-    if (t.root < 0) return fail(PFQ_ERR_STATE, "query on an empty tree");
-    PFQ_TRY(build_layout(t));
-    const bool want_hits = (flags & PFQ_WANT_HITS) != 0;
-    if (want_hits && !hits) return fail(PFQ_ERR_ARG, "PFQ_WANT_HITS set but hits == NULL");
-    if (n_reads >= (1ull << 31) - 1024) return fail(PFQ_ERR_ARG, "more than 2^31 reads in one block");
-    // the scratch buffers are reused call after call: calls on one stream are ordered by it, a change of stream waits
-    if (t.have_last_stream && t.last_stream != st) HIP_TRY(hipStreamSynchronize(t.last_stream));
-    t.last_stream = st;
-    t.have_last_stream = true;
-    t.last_n_reads = n_reads;
-    PFQ_TRY(ensure_scratch(t, n_reads, want_hits));
-    const size_t nl = t.leaves.size();
-    size_t nc = t.n_cols;  // leaf + guard columns = buckets of the bucketed path (block mode: blocks of 8 leaf columns)
-    const bool with_guards = !t.guard_col.empty();
-    // bucketed path: threshold 1 (any certificate kernel), or 0 < threshold < 1 with probe records (per-pair k-mer miss bits)
-    const bool thr_one = threshold == 1.0f, thr_frac = threshold > 0.0f && threshold < 1.0f;
-    const Knobs &kn = t.knobs;
-    // budgets of the two large scratch buffers: what the device can still give (plus what the tree already holds of it),
-    // at most 64 GB each, unless a knob says otherwise; a failed allocation degrades to the next exact path below
-    size_t mem_free = 0, mem_total = 0;
-    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = 0; }
-    uint64_t rec_budget = std::min<uint64_t>(64ull << 30, (uint64_t)((double)(mem_free + t.d_recs.bytes()) * 0.45));
-    if (kn.record_gb >= 0) rec_budget = (uint64_t)kn.record_gb << 30;
-    bool recs_possible = total_bytes && t.nbits < (1ull << 30) && t.num_hashes <= 35 && total_bytes * 16 <= rec_budget;
-    // (or as many bases as 2^18 reads of 150 bp: long reads bring the same certificate work with fewer reads)
-    bool bucketed = (t.force_path == 1) || (t.force_path < 0 && (n_reads >= BUCKET_MIN_READS || total_bytes >= BUCKET_MIN_READS * 150));
-    if (!(thr_one || thr_frac) || nl == 0 || n_reads == 0) bucketed = false;
-    // probe records: hash survivors once instead of once per slice (needs d < 2^30, <= 35 hashes, room)
-    if (bucketed && recs_possible && !soft_ensure(t.d_recs, total_bytes + 64)) recs_possible = false;
-    if (bucketed && thr_frac && !recs_possible) bucketed = false;  // the miss bits of thresholds < 1 come from the records
-    // the classify launches of this call: one per group of leaf columns (two for thresholds < 1: reads of >= 256 k-mers), on
-    // all reads, or — two-level frontier — on the reads the coarse launch lists for the group
-    const uint32_t group_cols = 1u << t.group_log2;
-    const uint32_t leaf_groups = (uint32_t)std::max<size_t>(1, (nl + group_cols - 1) / group_cols);
-    const int blocks = (int)std::min<uint64_t>((n_reads + 3) / 4, CLASSIFY_MAX_BLOCKS);  // (2048: 10.1 ms, 4096: 9.9 ms per step)
-    const bool want_two_level = t.coarse_valid && leaf_groups > 1 && (kn.coarse > 0 || threshold >= 1.0f || t.coarse_fill <= 0.70);
-    const int blocks_group = want_two_level ? std::min(blocks, 1024) : blocks;  // (a list holds a fraction of the reads)
-    const uint64_t launch_waves = 4ull * (uint64_t)blocks_group * leaf_groups * (threshold >= 1.0f ? 1 : 2);
-    if (bucketed && !ensure_bucket_scratch(t, n_reads, with_guards, launch_waves)) bucketed = false;
-    if (bucketed && recs_possible && !soft_ensure(t.d_meta, t.d_pairs.n)) recs_possible = false;
-    if (bucketed && thr_frac && !recs_possible) bucketed = false;
-    const bool counts_mode = !(threshold >= 1.0f);  // theta >= 1: need >= n for every read with k-mers
-    // Block mode (pfq::TILE_LOG2_BLOCK): reads that pass several leaves of a block of 8 (strains of one phage) are certified
-    // once per block.  Threshold 1, no guard columns, records and room for the tables; chosen when recent calls saw more
-    // than 1.5 candidate leaves per read (PFQ_BLOCK=1 / 0 forces / forbids it).  Results do not depend on the choice.
-    const uint64_t n_blocks = (nl + 7) / 8;
-    const uint32_t n_tiles_block = (uint32_t)((t.n_words * 64 + (1ull << pfq::TILE_LOG2_BLOCK) - 1) >> pfq::TILE_LOG2_BLOCK);
-    // (Guard columns — reference-built trees whose internal names collide: the guards of a hit are certified against the
-    // sliced matrix afterwards, 1300 line gathers each, which pays while few leaves have guards: <= 5 % of them.)
-    size_t guarded = 0;
-    for (size_t c = 0; with_guards && c < nl; ++c) guarded += t.guard_off[c + 1] > t.guard_off[c];
-    // Candidate leaves per read decide between the pair pipeline and block mode.  Later calls take the figure of the call
-    // before; a call without that history (the first on a tree, the first after its layout changed) screens a sample of its
-    // OWN reads first — the frontier only, nothing is certified or counted — so that a workload of related genomes does not
-    // run its first block through the pair pipeline.  One small launch per column group and one read-back.
-    const bool block_eligible = bucketed && (thr_one || (thr_frac && kn.tile_counts != 0)) && recs_possible && n_tiles_block <= 560 &&
-                                n_blocks < (1u << 16) && (kn.tile < 0 || kn.tile != 0);
-    if (block_eligible && kn.block < 0 && !t.have_cand_hint && guarded * 20 <= nl) {
+// One pfq_query_batch[_device] call.  plan() chooses the path and the modes from the tree, the threshold, the knobs, the room
+// the device has left and — block mode, on a tree without history — a screened sample of the block's own reads; attempt() is
+// one run of the kernels (a second one only when the hit buffer proved too small), stage by stage: frontier(), then on the
+// bucketed path setup_pairs() -> frontier(true) -> expand guards / tail records -> bucket_sort() -> setup_verify() ->
+// tile_stage() -> finish_blocks() or finish_pairs(); read_hits() brings the per-read hit lists back.  Everything is queued on
+// `st`; results never depend on which modes were chosen.
+struct QueryRun {
+    pfq_tree &t;
+    const uint8_t *d_seq;
+    const uint64_t *d_off;
+    uint64_t n_reads, total_bytes;
+    float threshold;
+    uint32_t flags;
+    hipStream_t st;
+    pfq_hits *hits;
+    const Knobs &kn;
+    // ---- the plan
+    bool want_hits = false, with_guards = false, thr_one = false, thr_frac = false, counts_mode = false;
+    bool recs_possible = false, bucketed = false, block_mode = false, want_two_level = false;
+    size_t nl = 0, nc = 0, guarded = 0, nb = 0, mem_free = 0, mem_total = 0;
+    uint32_t group_cols = 0, leaf_groups = 1, n_tiles_block = 0, sub_log2 = 0;
+    int blocks = 0, blocks_group = 0;
+    uint64_t launch_waves = 0, n_blocks = 0, miss_cap = 0, hit_cap = 0;
+    // ---- one attempt
+    pfq::QueryArgs a{};
+    hipEvent_t *ev = nullptr;
+    uint32_t *cnt = nullptr, *off = nullptr, *cur = nullptr, *cntw = nullptr, *offw = nullptr, *curw = nullptr;  // bucket histograms / offsets / cursors
+    uint4 *recs = nullptr;
+    uint32_t n_slices = 1;
+    pfq::GuardArgs ga{};
+    pfq::VerifyArgs v{};
+    int vblocks = 512, vthreads = 512;
+
+    QueryRun(pfq_tree &t_, const uint8_t *seq_, const uint64_t *off_, uint64_t n_, uint64_t bytes_, float thr_, uint32_t flags_, hipStream_t st_,
+             pfq_hits *hits_)
+        : t(t_), d_seq(seq_), d_off(off_), n_reads(n_), total_bytes(bytes_), threshold(thr_), flags(flags_), st(st_), hits(hits_), kn(t_.knobs) {}
+
+    int plan() {
+        if (t.root < 0) return fail(PFQ_ERR_STATE, "query on an empty tree");
+        PFQ_TRY(build_layout(t));
+        want_hits = (flags & PFQ_WANT_HITS) != 0;
+        if (want_hits && !hits) return fail(PFQ_ERR_ARG, "PFQ_WANT_HITS set but hits == NULL");
+        if (n_reads >= (1ull << 31) - 1024) return fail(PFQ_ERR_ARG, "more than 2^31 reads in one block");
+        // the scratch buffers are reused call after call: calls on one stream are ordered by it, a change of stream waits
+        if (t.have_last_stream && t.last_stream != st) HIP_TRY(hipStreamSynchronize(t.last_stream));
+        t.last_stream = st;
+        t.have_last_stream = true;
+        t.last_n_reads = n_reads;
+        PFQ_TRY(ensure_scratch(t, n_reads, want_hits));
+        nl = t.leaves.size();
+        nc = t.n_cols;  // leaf + guard columns = buckets of the bucketed path (block mode: blocks of 8 leaf columns)
+        with_guards = !t.guard_col.empty();
+        // bucketed path: threshold 1 (any certificate kernel), or 0 < threshold < 1 with probe records (per-pair k-mer miss bits)
+        thr_one = threshold == 1.0f;
+        thr_frac = threshold > 0.0f && threshold < 1.0f;
+        // budgets of the two large scratch buffers: what the device can still give (plus what the tree already holds of it),
+        // at most 64 GB each, unless a knob says otherwise; a failed allocation degrades to the next exact path below
+        if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = 0; }
+        uint64_t rec_budget = std::min<uint64_t>(64ull << 30, (uint64_t)((double)(mem_free + t.d_recs.bytes()) * 0.45));
+        if (kn.record_gb >= 0) rec_budget = (uint64_t)kn.record_gb << 30;
+        recs_possible = total_bytes && t.nbits < (1ull << 30) && t.num_hashes <= 35 && total_bytes * 16 <= rec_budget;
+        // (or as many bases as 2^18 reads of 150 bp: long reads bring the same certificate work with fewer reads)
+        bucketed = (t.force_path == 1) || (t.force_path < 0 && (n_reads >= BUCKET_MIN_READS || total_bytes >= BUCKET_MIN_READS * 150));
+        if (!(thr_one || thr_frac) || nl == 0 || n_reads == 0) bucketed = false;
+        // probe records: hash survivors once instead of once per slice (needs d < 2^30, <= 35 hashes, room)
+        if (bucketed && recs_possible && !soft_ensure(t.d_recs, total_bytes + 64)) recs_possible = false;
+        if (bucketed && thr_frac && !recs_possible) bucketed = false;  // the miss bits of thresholds < 1 come from the records
+        // the classify launches of this call: one per group of leaf columns (two for thresholds < 1: reads of >= 256 k-mers), on
+        // all reads, or — two-level frontier — on the reads the coarse launch lists for the group
+        group_cols = 1u << t.group_log2;
+        leaf_groups = (uint32_t)std::max<size_t>(1, (nl + group_cols - 1) / group_cols);
+        blocks = (int)std::min<uint64_t>((n_reads + 3) / 4, CLASSIFY_MAX_BLOCKS);  // (2048: 10.1 ms, 4096: 9.9 ms per step)
+        want_two_level = t.coarse_valid && leaf_groups > 1 && (kn.coarse > 0 || threshold >= 1.0f || t.coarse_fill <= 0.70);
+        blocks_group = want_two_level ? std::min(blocks, 1024) : blocks;  // (a list holds a fraction of the reads)
+        launch_waves = 4ull * (uint64_t)blocks_group * leaf_groups * (threshold >= 1.0f ? 1 : 2);
+        if (bucketed && !ensure_bucket_scratch(t, n_reads, with_guards, launch_waves)) bucketed = false;
+        if (bucketed && recs_possible && !soft_ensure(t.d_meta, t.d_pairs.n)) recs_possible = false;
+        if (bucketed && thr_frac && !recs_possible) bucketed = false;
+        counts_mode = !(threshold >= 1.0f);  // theta >= 1: need >= n for every read with k-mers
+        // Block mode (pfq::TILE_LOG2_BLOCK): reads that pass several leaves of a block of 8 (strains of one phage) are certified
+        // once per block.  Threshold 1, no guard columns, records and room for the tables; chosen when recent calls saw more
+        // than 1.5 candidate leaves per read (PFQ_BLOCK=1 / 0 forces / forbids it).  Results do not depend on the choice.
+        n_blocks = (nl + 7) / 8;
+        n_tiles_block = (uint32_t)((t.n_words * 64 + (1ull << pfq::TILE_LOG2_BLOCK) - 1) >> pfq::TILE_LOG2_BLOCK);
+        // (Guard columns — reference-built trees whose internal names collide: the guards of a hit are certified against the
+        // sliced matrix afterwards, 1300 line gathers each, which pays while few leaves have guards: <= 5 % of them.)
+        guarded = 0;
+        for (size_t c = 0; with_guards && c < nl; ++c) guarded += t.guard_off[c + 1] > t.guard_off[c];
+        // Candidate leaves per read decide between the pair pipeline and block mode.  Later calls take the figure of the call
+        // before; a call without that history (the first on a tree, the first after its layout changed) screens a sample of its
+        // OWN reads first — the frontier only, nothing is certified or counted — so that a workload of related genomes does not
+        // run its first block through the pair pipeline.  One small launch per column group and one read-back.
+        const bool block_eligible = bucketed && (thr_one || (thr_frac && kn.tile_counts != 0)) && recs_possible && n_tiles_block <= 560 &&
+                                    n_blocks < (1u << 16) && (kn.tile < 0 || kn.tile != 0);
+        if (block_eligible && kn.block < 0 && !t.have_cand_hint && guarded * 20 <= nl) PFQ_TRY(sample_candidates());
+        // At thresholds below 1 block mode keeps the k-mer entries: buckets by (block, candidate mask), 8 miss bytes per k-mer.
+        block_mode = block_eligible && (kn.block >= 0 ? kn.block != 0 : (t.cand_per_read > 1.5 && guarded * 20 <= nl));
+        if (block_mode && !soft_ensure(t.d_T, n_blocks * t.n_words * 64)) block_mode = false;
+        if (block_mode && !soft_ensure(t.d_failb, t.d_pairs.n * 8)) block_mode = false;
+        if (block_mode) nc = n_blocks * 256;  // buckets by (block, candidate mask)
+        t.last_block_mode = 0;
+        miss_cap = 0;
+        nb = 0;
+        sub_log2 = 0;
+        if (bucketed) {
+            // sub-buckets (keyed by the read index) keep every histogram counter cold when columns are few
+            while (sub_log2 < 6 && (nc << sub_log2) < 1024) ++sub_log2;
+            nb = nc << sub_log2;
+            if (block_mode && !soft_ensure(t.d_bucket, 3 * nb + 2)) bucketed = false;  // (buckets by (block, mask) outnumber the columns of small trees)
+            if (counts_mode && !block_mode) {  // thresholds < 1: every deferred pair owns ceil(n/64) words of k-mer miss bits that the slices OR into
+                const uint64_t avg_len = n_reads ? total_bytes / n_reads : 0;
+                miss_cap = std::min<uint64_t>((t.leaf_cap + t.guard_cap) * ((avg_len >> 6) + 2) + (launch_waves + 4 * 2048) * (uint64_t)pfq::MISS_RESERVE, 0xfffffff0ull);
+                if (!(soft_ensure(t.d_miss_words, miss_cap) && soft_ensure(t.d_miss_pos, t.d_pairs.n) && soft_ensure(t.d_bucket_w, 3 * nb + 2)))
+                    bucketed = false;
+            }
+        }
+        t.last_path = bucketed ? 1 : 0;
+        hit_cap = t.d_hit_pairs.n;
+        return PFQ_OK;
+    }
+
+    // Candidates per read of the first reads of this block: the frontier only, nothing is certified or counted.
+    int sample_candidates() {
         const uint64_t n_s = std::min<uint64_t>(n_reads, 16384);
         HIP_TRY(hipMemsetAsync(t.d_stats.p, 0, pfq::ST_N * 8, st));
         HIP_TRY(hipMemsetAsync(t.d_cursors.p, 0, 128, st));
@@ -927,42 +990,110 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
         HIP_TRY(hipStreamSynchronize(st));
         t.cand_per_read = (double)cand / (double)n_s;
         t.have_cand_hint = true;
+        return PFQ_OK;
     }
-    // At thresholds below 1 block mode keeps the k-mer entries: buckets by (block, candidate mask), 8 miss bytes per k-mer.
-    bool block_mode = bucketed && (thr_one || (thr_frac && kn.tile_counts != 0)) && recs_possible && n_tiles_block <= 560 && n_blocks < (1u << 16) &&
-                      (kn.block >= 0 ? kn.block != 0 : (t.cand_per_read > 1.5 && guarded * 20 <= nl)) && (kn.tile < 0 || kn.tile != 0);
-    if (block_mode && !soft_ensure(t.d_T, n_blocks * t.n_words * 64)) block_mode = false;
-    if (block_mode && !soft_ensure(t.d_failb, t.d_pairs.n * 8)) block_mode = false;
-    if (block_mode) nc = n_blocks * 256;  // buckets by (block, candidate mask)
-    t.last_block_mode = 0;
-    uint64_t miss_cap = 0;
-    size_t nb = 0;
-    uint32_t sub_log2 = 0;
-    if (bucketed) {
-        // sub-buckets (keyed by the read index) keep every histogram counter cold when columns are few
-        while (sub_log2 < 6 && (nc << sub_log2) < 1024) ++sub_log2;
-        nb = nc << sub_log2;
-        if (block_mode && !soft_ensure(t.d_bucket, 3 * nb + 2)) bucketed = false;  // (buckets by (block, mask) outnumber the columns of small trees)
-        if (counts_mode && !block_mode) {  // thresholds < 1: every deferred pair owns ceil(n/64) words of k-mer miss bits that the slices OR into
-            const uint64_t avg_len = n_reads ? total_bytes / n_reads : 0;
-            miss_cap = std::min<uint64_t>((t.leaf_cap + t.guard_cap) * ((avg_len >> 6) + 2) + (launch_waves + 4 * 2048) * (uint64_t)pfq::MISS_RESERVE, 0xfffffff0ull);
-            if (!(soft_ensure(t.d_miss_words, miss_cap) && soft_ensure(t.d_miss_pos, t.d_pairs.n) && soft_ensure(t.d_bucket_w, 3 * nb + 2)))
-                bucketed = false;
-        }
-    }
-    t.last_path = bucketed ? 1 : 0;
 
-    uint64_t hit_cap = t.d_hit_pairs.n;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    // the frontier kernels, once per column group that holds leaves (a tree of up to 2048 columns has one group)
+    int frontier(bool defer) {
+        // Two-level frontier: the coarse launch screens every read against an antichain of internal nodes and lists
+        // it for the leaf groups below its live columns; a group's launch then sees only its list.
+        // (thresholds < 1: only while the coarse filters are empty enough for <= 4 probes per k-mer to tell a miss)
+        bool two_level = want_two_level;
+        uint32_t list_cap = 0;
+        if (two_level) {
+            // every read at most once per list + one partly used reservation of 32 per wave of the (two) coarse launches
+            list_cap = (uint32_t)((n_reads + 2 * 32ull * 4 * (uint64_t)blocks + 63) & ~31ull);
+            if (!soft_ensure(t.d_glists, (size_t)list_cap * leaf_groups)) two_level = false;
+            if (two_level && counts_mode && !soft_ensure(t.d_glong, (size_t)list_cap * leaf_groups)) two_level = false;
+        }
+        t.last_leaf_groups = leaf_groups;
+        t.last_coarse_cols = t.last_coarse_probes = 0;
+        if (two_level) {
+            pfq::QueryArgs ac = a;
+            ac.S = ac.S_all = t.d_Sc.p;
+            ac.group_stride = 0;
+            ac.group_log2 = 11;
+            ac.col0 = 0;
+            ac.n_leaves = ac.n_cols = t.coarse_cols;
+            ac.rw = t.coarse_rw;
+            ac.rw_log2 = t.coarse_rw_log2;
+            ac.first_group = 1;
+            pfq::CoarseArgs ca{};
+            ca.cgrp = t.d_cgrp.p;
+            ca.n_groups = leaf_groups;
+            ca.lists = t.d_glists.p;
+            ca.cursors = t.d_gcur.p;
+            ca.list_cap = list_cap;
+            ca.total_leaves = (uint32_t)nl;
+            // probes per k-mer: enough for a foreign read to lose every coarse column.  Threshold 1 (AND over 4 k-mers):
+            // columns x fill^(4 p) <= 0.02; below 1: a k-mer must be a miss with probability >= 0.85, 1 - fill^p
+            const double f = std::min(0.999, std::max(1e-6, t.coarse_fill));
+            uint32_t np;
+            if (!counts_mode) {
+                np = (uint32_t)std::ceil(std::log(0.02 / t.coarse_cols) / (4.0 * std::log(f)));
+                np = std::min<uint32_t>(std::max<uint32_t>(np, 2), pfq::COARSE_MAX_PROBES);
+            } else {
+                np = 1;
+                while (np < 4 && 1.0 - std::pow(f, (double)np) < 0.85) ++np;
+                // k-mers looked at beyond maxmiss + 1 + 8, per 256 of maxmiss + 1: what the k-mers that are no misses cost
+                const double pm = 1.0 - std::pow(f, (double)np);
+                ca.scr_extra = (uint32_t)std::min(256.0, std::ceil(256.0 * (1.0 / pm - 1.0)));
+            }
+            if (kn.coarse_probes > 0) np = (uint32_t)std::min<long long>(kn.coarse_probes, counts_mode ? 4 : pfq::COARSE_MAX_PROBES);
+            np = std::max<uint32_t>(1, std::min<uint32_t>(np, t.num_hashes));
+            ca.n_probes = np;
+            t.last_coarse_cols = t.coarse_cols;
+            t.last_coarse_probes = np;
+            HIP_TRY(hipMemsetAsync(t.d_gcur.p, 0, 2 * pfq::MAX_LEAF_GROUPS * sizeof(unsigned int), st));  // lists' cursors, long reads' cursors
+            pfq::launch_coarse(ac, ca, counts_mode, blocks, st);
+        }
+        if (two_level) {
+            // ONE launch for all leaf groups (blockIdx.y = the group: its matrix, columns and list follow from it); the
+            // queues of reads of >= 256 k-mers (thresholds < 1) are per group as well, behind the groups' cursors
+            a.S = t.d_S.p;
+            a.col0 = 0;
+            a.n_leaves = (uint32_t)std::min<size_t>(group_cols, nl);
+            a.first_group = 0;
+            a.read_list = t.d_glists.p;
+            a.n_list = t.d_gcur.p;
+            a.grid_groups = leaf_groups;
+            a.total_leaves = (uint32_t)nl;
+            a.list_cap = list_cap;
+            if (counts_mode) {
+                a.long_list = t.d_glong.p;
+                a.n_long = t.d_gcur.p + pfq::MAX_LEAF_GROUPS;
+            }
+            pfq::launch_classify(a, defer, counts_mode, blocks_group, st);
+            a.read_list = nullptr;
+            a.n_list = nullptr;
+            a.grid_groups = 0;
+            if (counts_mode) {
+                a.long_list = t.d_long.p;
+                a.n_long = reinterpret_cast<unsigned int *>(t.d_cursors.p + 4);
+            }
+            return PFQ_OK;
+        }
+        for (uint32_t g = 0; g < leaf_groups; ++g) {
+            a.S = t.d_S.p + (uint64_t)g * t.group_stride;
+            a.col0 = g * group_cols;
+            a.n_leaves = (uint32_t)std::min<size_t>(group_cols, nl - (size_t)g * group_cols);
+            a.first_group = g == 0;
+            if (g && counts_mode) HIP_TRY(hipMemsetAsync(t.d_cursors.p + 4, 0, 8, st));  // the queue of long reads is per launch
+            pfq::launch_classify(a, defer, counts_mode, blocks, st);
+        }
+        return PFQ_OK;
+    }
+
+    int attempt(int attempt_no) {
         HIP_TRY(hipMemsetAsync(t.d_stats.p, 0, pfq::ST_N * 8, st));
         HIP_TRY(hipMemsetAsync(t.d_cursors.p, 0, 128, st));
         if (want_hits) {
             HIP_TRY(hipMemsetAsync(t.d_allhit.p, 0, n_reads + 1, st));
-            if (attempt == 0 && nl)
+            if (attempt_no == 0 && nl)
                 HIP_TRY(hipMemcpyAsync(t.d_counts_snapshot.p, t.d_counts.p, nl * 8, hipMemcpyDeviceToDevice, st));
         }
         if (n_reads && nl) {
-            pfq::QueryArgs a{};
+            a = pfq::QueryArgs{};
             a.hp = t.hp;
             a.seq = d_seq;
             a.off = d_off;
@@ -988,97 +1119,7 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
                 a.long_list = t.d_long.p;
                 a.n_long = reinterpret_cast<unsigned int *>(t.d_cursors.p + 4);
             }
-            // the frontier kernels, once per column group that holds leaves (a tree of up to 2048 columns has one group)
-            auto classify_groups = [&](bool defer) -> int {
-                // Two-level frontier: the coarse launch screens every read against an antichain of internal nodes and lists
-                // it for the leaf groups below its live columns; a group's launch then sees only its list.
-                // (thresholds < 1: only while the coarse filters are empty enough for <= 4 probes per k-mer to tell a miss)
-                bool two_level = want_two_level;
-                uint32_t list_cap = 0;
-                if (two_level) {
-                    // every read at most once per list + one partly used reservation of 32 per wave of the (two) coarse launches
-                    list_cap = (uint32_t)((n_reads + 2 * 32ull * 4 * (uint64_t)blocks + 63) & ~31ull);
-                    if (!soft_ensure(t.d_glists, (size_t)list_cap * leaf_groups)) two_level = false;
-                    if (two_level && counts_mode && !soft_ensure(t.d_glong, (size_t)list_cap * leaf_groups)) two_level = false;
-                }
-                t.last_leaf_groups = leaf_groups;
-                t.last_coarse_cols = t.last_coarse_probes = 0;
-                if (two_level) {
-                    pfq::QueryArgs ac = a;
-                    ac.S = ac.S_all = t.d_Sc.p;
-                    ac.group_stride = 0;
-                    ac.group_log2 = 11;
-                    ac.col0 = 0;
-                    ac.n_leaves = ac.n_cols = t.coarse_cols;
-                    ac.rw = t.coarse_rw;
-                    ac.rw_log2 = t.coarse_rw_log2;
-                    ac.first_group = 1;
-                    pfq::CoarseArgs ca{};
-                    ca.cgrp = t.d_cgrp.p;
-                    ca.n_groups = leaf_groups;
-                    ca.lists = t.d_glists.p;
-                    ca.cursors = t.d_gcur.p;
-                    ca.list_cap = list_cap;
-                    ca.total_leaves = (uint32_t)nl;
-                    // probes per k-mer: enough for a foreign read to lose every coarse column.  Threshold 1 (AND over 4 k-mers):
-                    // columns x fill^(4 p) <= 0.02; below 1: a k-mer must be a miss with probability >= 0.85, 1 - fill^p
-                    const double f = std::min(0.999, std::max(1e-6, t.coarse_fill));
-                    uint32_t np;
-                    if (!counts_mode) {
-                        np = (uint32_t)std::ceil(std::log(0.02 / t.coarse_cols) / (4.0 * std::log(f)));
-                        np = std::min<uint32_t>(std::max<uint32_t>(np, 2), pfq::COARSE_MAX_PROBES);
-                    } else {
-                        np = 1;
-                        while (np < 4 && 1.0 - std::pow(f, (double)np) < 0.85) ++np;
-                        // k-mers looked at beyond maxmiss + 1 + 8, per 256 of maxmiss + 1: what the k-mers that are no misses cost
-                        const double pm = 1.0 - std::pow(f, (double)np);
-                        ca.scr_extra = (uint32_t)std::min(256.0, std::ceil(256.0 * (1.0 / pm - 1.0)));
-                    }
-                    if (kn.coarse_probes > 0) np = (uint32_t)std::min<long long>(kn.coarse_probes, counts_mode ? 4 : pfq::COARSE_MAX_PROBES);
-                    np = std::max<uint32_t>(1, std::min<uint32_t>(np, t.num_hashes));
-                    ca.n_probes = np;
-                    t.last_coarse_cols = t.coarse_cols;
-                    t.last_coarse_probes = np;
-                    HIP_TRY(hipMemsetAsync(t.d_gcur.p, 0, 2 * pfq::MAX_LEAF_GROUPS * sizeof(unsigned int), st));  // lists' cursors, long reads' cursors
-                    pfq::launch_coarse(ac, ca, counts_mode, blocks, st);
-                }
-                if (two_level) {
-                    // ONE launch for all leaf groups (blockIdx.y = the group: its matrix, columns and list follow from it); the
-                    // queues of reads of >= 256 k-mers (thresholds < 1) are per group as well, behind the groups' cursors
-                    a.S = t.d_S.p;
-                    a.col0 = 0;
-                    a.n_leaves = (uint32_t)std::min<size_t>(group_cols, nl);
-                    a.first_group = 0;
-                    a.read_list = t.d_glists.p;
-                    a.n_list = t.d_gcur.p;
-                    a.grid_groups = leaf_groups;
-                    a.total_leaves = (uint32_t)nl;
-                    a.list_cap = list_cap;
-                    if (counts_mode) {
-                        a.long_list = t.d_glong.p;
-                        a.n_long = t.d_gcur.p + pfq::MAX_LEAF_GROUPS;
-                    }
-                    pfq::launch_classify(a, defer, counts_mode, blocks_group, st);
-                    a.read_list = nullptr;
-                    a.n_list = nullptr;
-                    a.grid_groups = 0;
-                    if (counts_mode) {
-                        a.long_list = t.d_long.p;
-                        a.n_long = reinterpret_cast<unsigned int *>(t.d_cursors.p + 4);
-                    }
-                    return PFQ_OK;
-                }
-                for (uint32_t g = 0; g < leaf_groups; ++g) {
-                    a.S = t.d_S.p + (uint64_t)g * t.group_stride;
-                    a.col0 = g * group_cols;
-                    a.n_leaves = (uint32_t)std::min<size_t>(group_cols, nl - (size_t)g * group_cols);
-                    a.first_group = g == 0;
-                    if (g && counts_mode) HIP_TRY(hipMemsetAsync(t.d_cursors.p + 4, 0, 8, st));  // the queue of long reads is per launch
-                    pfq::launch_classify(a, defer, counts_mode, blocks, st);
-                }
-                return PFQ_OK;
-            };
-            hipEvent_t *ev = nullptr;
+            ev = nullptr;
             if (t.prof_used < t.prof_cap) {
                 ev = &t.prof_ev[PROF_EV * t.prof_used];
                 t.prof_bucketed[t.prof_used] = bucketed;
@@ -1086,340 +1127,16 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             }
             if (ev) HIP_TRY(hipEventRecord(ev[0], st));
             if (bucketed) {
-                t.last_sub_log2 = sub_log2;
-                uint32_t *cnt = t.d_bucket.p, *off = cnt + nb, *cur = off + nb + 1;
-                a.pairs = t.d_pairs.p;
-                a.pair_cap = t.leaf_cap;  // whole reservations only (PAIR_CHUNK = 32)
-                a.pair_cursor = t.d_cursors.p + 1;
-                a.bucket_cnt = cnt;
-                a.sub_log2 = sub_log2;
-                uint4 *recs = recs_possible ? t.d_recs.p : nullptr;
-                a.recs = recs;
-                a.rec_cap = recs ? t.d_recs.n : 0;
-                uint32_t *cntw = nullptr, *offw = nullptr, *curw = nullptr;
-                if (counts_mode && !block_mode) {
-                    cntw = t.d_bucket_w.p;
-                    offw = cntw + nb;
-                    curw = offw + nb + 1;
-                    HIP_TRY(hipMemsetAsync(t.d_miss_words.p, 0, miss_cap * 8, st));
-                    HIP_TRY(hipMemsetAsync(cntw, 0, nb * 4, st));
-                    a.bucket_words = cntw;
-                    a.miss_cursor = t.d_cursors.p + 5;
-                    a.miss_cap = miss_cap;
-                }
-                uint32_t n_slices = 1;
-                uint64_t slice_target = SLICE_TARGET_BYTES;
-                if (kn.slice_kb > 0) slice_target = (uint64_t)kn.slice_kb << 10;
-                while (n_slices < 8 && (t.n_words * 8 + n_slices - 1) / n_slices > slice_target) n_slices <<= 1;
-                t.last_slices = n_slices;
-                HIP_TRY(hipMemsetAsync(cnt, 0, nb * 4, st));
-                HIP_TRY(hipMemsetAsync(t.d_fail.p, 0, t.d_fail.n * 4, st));
-                if (with_guards) HIP_TRY(hipMemsetAsync(t.d_gfail.p, 0, t.d_gfail.n * 4, st));
-                HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 128 * 4, st));
-                a.batch_tails = (recs && !counts_mode && kn.no_tail_batch <= 0) ? 1u : 0u;
-                a.block_pairs = block_mode ? 1u : 0u;
-                a.screen_recs = kn.screen_recs >= 0 ? (uint32_t)(kn.screen_recs != 0) : 1u;
-                if (block_mode) {
-                    if (!t.tables_valid) {  // (the leaf set changed, or first use)
-                        pfq::launch_block_tables(t.d_bits.p, t.n_words, t.d_col_row.p, (uint32_t)nl, t.d_T.p, st);
-                        t.tables_valid = true;
-                    }
-                    HIP_TRY(hipMemsetAsync(t.d_failb.p, 0, t.d_failb.n, st));
-                }
-                PFQ_TRY(classify_groups(true));
-                pfq::GuardArgs ga{};
-                if (with_guards && !block_mode) {  // every guard of a deferred pair's leaf becomes a pair of its own (second region of the buffer)
-                    ga.pairs = t.d_pairs.p + t.leaf_cap;
-                    ga.cap = t.guard_cap;
-                    ga.cursor = t.d_cursors.p + 8;
-                    ga.slot0 = (uint32_t)t.leaf_cap;
-                    ga.owner = t.d_owner.p;
-                    ga.gfail = t.d_gfail.p;
-                    pfq::launch_expand_guards(a, ga, 2048, st);
-                }
-                if (a.batch_tails) pfq::launch_tail_records(a, 2048, st);
-                if (ev) HIP_TRY(hipEventRecord(ev[1], st));
-                pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nb, st);
-                if (counts_mode && !block_mode) pfq::launch_bucket_scan(cntw, offw, curw, (uint32_t)nb, st);
-                pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, sub_log2, t.d_sorted.p,
-                                           recs ? t.d_meta.p : nullptr, d_off, block_mode ? nullptr : t.d_col_row.p, offw, curw,
-                                           (counts_mode && !block_mode) ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
-                                           (with_guards && !block_mode) ? t.d_owner.p : nullptr,
-                                           (with_guards && !block_mode) ? t.d_owner_sorted.p : nullptr,
-                                           block_mode ? 2u : 0u, 1024, st);
-                if (with_guards && !block_mode)
-                    pfq::launch_bucket_scatter(ga.pairs, ga.cursor, ga.cap, off, cur, sub_log2, t.d_sorted.p,
-                                               recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, offw, curw,
-                                               counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
-                                               t.d_owner.p + t.leaf_cap, t.d_owner_sorted.p, 0u, 256, st);
-                if (ev) HIP_TRY(hipEventRecord(ev[2], st));
-                pfq::VerifyArgs v{};
-                v.hp = t.hp;
-                v.seq = d_seq;
-                v.off = d_off;
-                v.bits = t.d_bits.p;
-                v.col_row = t.d_col_row.p;
-                v.n_words = t.n_words;
-                v.sorted = t.d_sorted.p;
-                v.n_pairs_ptr = off + nb;
-                v.fail = t.d_fail.p;
-                v.recs = recs;
-                v.miss_words = (counts_mode && !block_mode) ? t.d_miss_words.p : nullptr;
-                v.miss_pos = (counts_mode && !block_mode) ? t.d_miss_pos.p : nullptr;
-                v.meta = t.d_meta.p;
-                v.n_slices = n_slices;
-                uint64_t sb = (t.n_words * 64 + n_slices - 1) / n_slices;
-                v.slice_bits = (uint32_t)((sb + 63) & ~63ull);
-                v.queue = t.d_queue.p;
-                // window of pairs in flight per slice = (blocks/8)*(8/n_slices)*4*chunk: about one leaf bucket
-                int vblocks = 512;
-                v.chunk = 1;
-                if (kn.verify_blocks >= 0) vblocks = std::max(8, (int)kn.verify_blocks & ~7);
-                if (kn.verify_chunk >= 0) v.chunk = (uint32_t)std::max(1, (int)kn.verify_chunk);
-                v.n_sub = 8;
-                if (kn.verify_sub >= 0) v.n_sub = (uint32_t)std::min(16, std::max(1, (int)kn.verify_sub));
-                int vthreads = 512;
-                if (kn.verify_threads >= 0) vthreads = std::min(1024, std::max(64, (int)kn.verify_threads & ~63));
-                if (!recs) { vthreads = 256; vblocks = 1024; v.chunk = 4; }  // re-hash fallback kernel: 4-wave blocks
-                // LDS-tile certificates: every probe binned by (leaf chunk, 128 KiB filter tile), tiles tested out of LDS;
-                // k_verify_rec then only sees the pairs that could not be binned
-                // (thresholds < 1: entries name k-mers, tiles are half the size — pfq::TILE_LOG2_COUNTS)
-                const uint32_t tile_log2 = block_mode ? pfq::TILE_LOG2_BLOCK : (counts_mode ? pfq::TILE_LOG2_COUNTS : pfq::TILE_LOG2);
-                const uint32_t n_tiles = (uint32_t)((t.n_words * 64 + (1ull << tile_log2) - 1) >> tile_log2);
-                const uint32_t chunk_log2 = pfq::CHUNK_PAIRS_LOG2;
-                // Thresholds < 1: the tile passes leave the k-mers that are not contained in per-chunk miss bitmaps; k_verify_rec
-                // only sees what could not be binned.  (PFQ_TILE_COUNTS=0: record kernel only.)  Results do not depend on the choice.
-                bool tile_counts = true;
-                if (kn.tile_counts >= 0) tile_counts = kn.tile_counts != 0;
-                bool tile_mode = recs && (!counts_mode || tile_counts) && (block_mode || n_tiles < 256);
-                if (kn.tile >= 0) tile_mode = tile_mode && kn.tile != 0;
-                if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = 0; }
-                uint64_t tile_budget = std::min<uint64_t>(64ull << 30, (uint64_t)((double)(mem_free + t.d_entries.bytes()) * 0.8));
-                if (kn.tile_gb >= 0) tile_budget = (uint64_t)kn.tile_gb << 30;
-                t.last_tile_mode = 0;
-                if (tile_mode) {
-                    // every read may survive with one candidate: (bases - (k-1) per read) * hashes * 1.125 + slack per bucket
-                    const uint64_t max_chunks = nc + ((t.leaf_cap + t.guard_cap) >> chunk_log2) + 2;
-                    uint64_t want = (uint64_t)((double)total_bytes * t.num_hashes * 1.13 * std::max(1.0, t.pairs_per_read)) +
-                                    max_chunks * n_tiles * 544ull;
-                    if (want * 4 > tile_budget) want = tile_budget / 4;
-                    if (kn.tile_entries >= 0) want = std::max<uint64_t>(1, (uint64_t)kn.tile_entries);  // tests: force passes
-                    // thresholds < 1: one miss byte per k-mer of every pair the recent calls make expect (chunks that find no room
-                    // take the fallback), the rounds' positions, the pairs' positions
-                    // (block mode: 8 bytes per k-mer, one per leaf of the block; chunk offsets are in 16-byte units)
-                    const uint64_t kmiss_cap = counts_mode ? std::min<uint64_t>(((uint64_t)((double)total_bytes * std::max(1.0, 1.3 * t.pairs_per_read)) + 16 * max_chunks + 64) * (block_mode ? 8u : 1u),
-                                                                                    block_mode ? (48ull << 30) : 0xfffffff0ull) & ~15ull : 0;
-                    bool ok = soft_ensure(t.d_entries, want) && soft_ensure(t.d_pair_chunk, t.d_pairs.n) && soft_ensure(t.d_flag_list, t.d_pairs.n) &&
-                              soft_ensure(t.d_leaf_chunk0, nc + 1) && soft_ensure(t.d_chunks, max_chunks) && soft_ensure(t.d_gfill, max_chunks * n_tiles) && soft_ensure(t.d_binq, 256);
-                    if (ok && counts_mode)
-                        ok = soft_ensure(t.d_kmiss, kmiss_cap) && soft_ensure(t.d_round_k0, max_chunks * pfq::MAX_ROUNDS) &&
-                             soft_ensure(t.d_n_rounds, max_chunks) && soft_ensure(t.d_pair_kpos, t.d_pairs.n);
-                    if (ok && counts_mode && block_mode) ok = soft_ensure(t.d_kall, (kmiss_cap >> 3) + 64);
-                    if (!ok) {
-                        tile_mode = false;  // not enough HBM for the probe buckets: stay with the record kernel
-                    } else {
-                        HIP_TRY(hipMemsetAsync(t.d_gfill.p, 0, max_chunks * n_tiles * 4, st));
-                        HIP_TRY(hipMemsetAsync(t.d_binq.p, 0, 256 * 4, st));
-                        pfq::TileArgs ta{};
-                        ta.hp = t.hp;
-                        ta.bits = t.d_bits.p;
-                        ta.n_words = t.n_words;
-                        ta.chunk_log2 = chunk_log2;
-                        if (block_mode) {  // the "filter" of a bucket is its block's table: n_words * 64 bytes
-                            ta.blocks = 1;
-                            if (counts_mode) ta.kall = t.d_kall.p;  // (buckets by (block, mask); the passes' columns are the blocks)
-                            ta.bits = reinterpret_cast<const uint64_t *>(t.d_T.p);
-                            ta.n_words = t.n_words * 8;
-                            ta.failb = t.d_failb.p;
-                        }
-                        ta.recs = recs;
-                        ta.meta = t.d_meta.p;
-                        ta.col_row = t.d_col_row.p;
-                        ta.bucket_off = off;
-                        ta.sub_log2 = sub_log2;
-                        ta.n_leaves = (uint32_t)(block_mode ? n_blocks : nc);  // (columns of the passes: blocks, whatever the buckets)
-                        ta.n_tiles = n_tiles;
-                        ta.chunks = t.d_chunks.p;
-                        ta.max_chunks = (uint32_t)max_chunks;
-                        ta.leaf_chunk0 = t.d_leaf_chunk0.p;
-                        ta.pair_chunk = t.d_pair_chunk.p;
-                        ta.n_chunks = reinterpret_cast<unsigned int *>(t.d_cursors.p + 3);
-                        ta.n_flagged = reinterpret_cast<unsigned int *>(t.d_cursors.p + 3) + 1;
-                        ta.flag_list = t.d_flag_list.p;
-                        ta.flag_cap = (uint32_t)std::min<uint64_t>(t.d_flag_list.n, 0xffffffffu);
-                        ta.entry_cursor = t.d_cursors.p + 2;
-                        // (a multiple of 32 entries: buckets then start on 128-byte boundaries, k_tile_test reads them 16 bytes at a time)
-                        ta.entry_cap = std::min<uint64_t>(want, t.d_entries.n) & ~31ull;  // (the buffer only grows; the budget of this call is `want`)
-                        ta.entries = t.d_entries.p;
-                        ta.gfill = t.d_gfill.p;
-                        ta.fail = t.d_fail.p;
-                        ta.n_pairs_ptr = off + nb;
-                        if (counts_mode) {
-                            ta.counts = 1;
-                            ta.threshold = threshold;
-                            ta.kmiss = t.d_kmiss.p;
-                            ta.kmiss_cap = kmiss_cap;
-                            ta.kmiss_used = t.d_cursors.p + 9;
-                            ta.round_k0 = t.d_round_k0.p;
-                            ta.n_rounds = t.d_n_rounds.p;
-                            ta.pair_kpos = t.d_pair_kpos.p;
-                            HIP_TRY(hipMemsetAsync(t.d_n_rounds.p, 0, max_chunks * 4, st));
-                        }
-                        int bin_blocks = 512, test_blocks = 512;
-                        if (kn.bin_blocks >= 0) bin_blocks = std::max(1, (int)kn.bin_blocks);
-                        if (kn.test_blocks >= 0) test_blocks = std::max(1, (int)kn.test_blocks);
-                        ta.bin_shape = kn.bin_narrow > 0 ? (uint32_t)kn.bin_narrow : (kn.bin_wide > 0 ? 2u : 0u);
-                        ta.debug = kn.bin_debug > 0 ? (uint32_t)kn.bin_debug : 0u;
-                        pfq::launch_tile_plan(ta, st);
-                        // The probe buckets of all pairs may exceed the buffer (reads that pass many leaves): the plan
-                        // spreads the chunks over passes that reuse it.  Their number is known on the device only; as
-                        // many passes as the previous call needed are launched without waiting, and chunks of later
-                        // passes (if any) are certified by the record kernel below — exact either way.
-                        uint64_t n_passes = std::min<uint64_t>(std::max<uint64_t>(1, t.passes_hint), 256);  // (more: the record kernel takes the rest)
-                        if (block_mode) {  // the fallback of block mode is slow: wait for the plan and launch every pass it needs
-                            HIP_TRY(hipMemcpyAsync(t.h_pair_cursor + 5, t.d_cursors.p + 2, 8, hipMemcpyDeviceToHost, st));
-                            HIP_TRY(hipStreamSynchronize(st));
-                            n_passes = ta.entry_cap ? std::min<uint64_t>(std::max<uint64_t>(1, (t.h_pair_cursor[5] + ta.entry_cap - 1) / ta.entry_cap), 256) : 1;
-                        }
-                        for (uint64_t p = 0; p < n_passes; ++p) {
-                            ta.pass = (uint32_t)p;
-                            ta.bin_queue = t.d_binq.p + p;
-                            pfq::launch_tile_bin(ta, bin_blocks, st);
-                            if (p == 0 && ev) HIP_TRY(hipEventRecord(ev[3], st));
-                            pfq::launch_tile_test(ta, test_blocks, st);
-                        }
-                        v.pair_chunk = t.d_pair_chunk.p;
-                        v.chunks = t.d_chunks.p;
-                        v.entry_cursor = t.d_cursors.p + 2;
-                        v.entry_cap = ta.entry_cap;
-                        v.launched_passes = (uint32_t)n_passes;
-                        if (counts_mode && !block_mode) {  // binned pairs whose prefix of k-mers leaves them undecided go to the record kernel
-                            pfq::FinalizeArgs pf{};
-                            pf.hp = t.hp;
-                            pf.threshold = threshold;
-                            pf.fail = t.d_fail.p;
-                            pf.kmiss = t.d_kmiss.p;
-                            pf.pair_kpos = t.d_pair_kpos.p;
-                            pf.pair_chunk = t.d_pair_chunk.p;
-                            pf.chunks = t.d_chunks.p;
-                            pf.launched_passes = (uint32_t)n_passes;
-                            pfq::launch_prefix_open(pf, t.d_meta.p, off + nb, t.d_fail.p, st);
-                        }
-                        t.hint_entry_cap = ta.entry_cap;
-                        t.last_passes = (uint32_t)std::max<uint64_t>(n_passes, 1);
-                        if (ev) HIP_TRY(hipEventRecord(ev[4], st));
-                        v.only_flagged = 1;
-                        v.n_flagged = ta.n_flagged;
-                        v.flag_list = t.d_flag_list.p;
-                        v.flag_cap = ta.flag_cap;
-                        t.last_tile_mode = 1;
-                    }
-                }
-                if (ev && !t.last_tile_mode) {
-                    HIP_TRY(hipEventRecord(ev[3], st));
-                    HIP_TRY(hipEventRecord(ev[4], st));
-                }
-                if (block_mode) {
-                    // what the passes did not bin (overflows, no room, or no passes at all) is certified leaf by leaf against S
-                    a.S = t.d_S.p;
-                    a.col0 = 0;
-                    a.n_leaves = (uint32_t)std::min<size_t>(2048, nl);
-                    if (counts_mode && t.last_tile_mode) {  // the miss bytes of the binned pairs decide their candidates
-                        pfq::FinalizeArgs cf{};
-                        cf.hp = t.hp;
-                        cf.off = d_off;
-                        cf.sorted = t.d_sorted.p;
-                        cf.threshold = threshold;
-                        cf.fail = t.d_fail.p;
-                        cf.kmiss = t.d_kmiss.p;
-                        cf.kall = t.d_kall.p;
-                        cf.pair_kpos = t.d_pair_kpos.p;
-                        cf.pair_chunk = t.d_pair_chunk.p;
-                        cf.chunks = t.d_chunks.p;
-                        cf.launched_passes = v.launched_passes;
-                        pfq::launch_block_count(cf, off + nb, t.d_failb.p, st);
-                    }
-                    pfq::launch_block_fallback(a, t.d_sorted.p, off + nb, t.d_fail.p, t.d_failb.p, t.d_pair_chunk.p,
-                                               t.last_tile_mode ? t.d_chunks.p : nullptr, v.launched_passes,
-                                               t.last_tile_mode ? v.n_flagged : nullptr, t.last_tile_mode ? v.flag_list : nullptr, v.flag_cap, st);
-                    // ancestors that are not provably supersets must pass too (query.rs:119-141): the guards of every candidate
-                    // that is still standing
-                    if (with_guards) pfq::launch_block_guards(a, t.d_sorted.p, off + nb, t.d_failb.p, st);
-                    if (ev) HIP_TRY(hipEventRecord(ev[5], st));
-                    pfq::FinalizeArgs f{};
-                    f.hp = t.hp;
-                    f.off = d_off;
-                    f.sorted = t.d_sorted.p;
-                    f.bucket_off = off;
-                    f.sub_log2 = sub_log2;
-                    f.threshold = threshold;
-                    f.counts = t.d_counts.p;
-                    f.hit_pairs = a.hit_pairs;
-                    f.hit_cap = hit_cap;
-                    f.hit_cursor = t.d_cursors.p;
-                    f.stats = t.d_stats.p;
-                    f.failb = t.d_failb.p;
-                    f.c0 = 0;
-                    f.c1 = (uint32_t)nc;
-                    pfq::launch_finalize(f, st);
-                    if (ev) HIP_TRY(hipEventRecord(ev[6], st));
-                    t.last_block_mode = 1;
-                    if (t.last_tile_mode) t.last_tile_mode = 2;
-                    t.hint_counts = false;
-                } else {
-                if (v.only_flagged == 1 && counts_mode) {
-                    // thresholds < 1: the list becomes every pair the tile passes left open (a k-mer missing, or not binned)
-                    unsigned int *n_open = reinterpret_cast<unsigned int *>(t.d_cursors.p + 7);
-                    pfq::launch_collect_open(t.d_fail.p, off + nb, t.d_flag_list.p, v.flag_cap, n_open, st);
-                    v.n_flagged = n_open;
-                }
-                pfq::launch_verify(v, vblocks, vthreads, st);
-                if (v.only_flagged == 1) {  // many flagged pairs (no room for their probe buckets): walk all pairs in leaf order instead
-                    v.only_flagged = 2;
-                    if (counts_mode) v.chunk = 8;  // (the walk pulls an item per 64 pairs, not per 8)
-                    pfq::launch_verify(v, vblocks, vthreads, st);
-                }
-                if (ev) HIP_TRY(hipEventRecord(ev[5], st));
-                pfq::FinalizeArgs f{};
-                f.hp = t.hp;
-                f.off = d_off;
-                f.sorted = t.d_sorted.p;
-                f.bucket_off = off;
-                f.sub_log2 = sub_log2;
-                f.fail = t.d_fail.p;
-                f.miss_words = v.miss_words;
-                f.miss_pos = v.miss_pos;
-                f.threshold = threshold;
-                f.counts = t.d_counts.p;
-                f.hit_pairs = a.hit_pairs;
-                f.hit_cap = hit_cap;
-                f.hit_cursor = t.d_cursors.p;
-                f.stats = t.d_stats.p;
-                f.n_dirty = t.d_cursors.p + 6;
-                if (counts_mode && t.last_tile_mode) {  // miss bits of the binned pairs: in their chunks' bitmaps
-                    f.kmiss = t.d_kmiss.p;
-                    f.pair_kpos = t.d_pair_kpos.p;
-                    f.pair_chunk = t.d_pair_chunk.p;
-                    f.chunks = t.d_chunks.p;
-                    f.launched_passes = v.launched_passes;
-                }
-                f.owner_sorted = with_guards ? t.d_owner_sorted.p : nullptr;
-                f.gfail = with_guards ? t.d_gfail.p : nullptr;
-                t.hint_counts = counts_mode;
-                if (with_guards) {  // the guard columns first: a guard that does not pass marks its leaf pair
-                    f.c0 = (uint32_t)nl;
-                    f.c1 = (uint32_t)nc;
-                    f.guards = 1;
-                    pfq::launch_finalize(f, st);
-                }
-                f.c0 = 0;
-                f.c1 = (uint32_t)nl;
-                f.guards = 0;
-                pfq::launch_finalize(f, st);
-                if (ev) HIP_TRY(hipEventRecord(ev[6], st));
-                }
+                PFQ_TRY(setup_pairs());
+                PFQ_TRY(frontier(true));
+                PFQ_TRY(guards_and_tails());
+                PFQ_TRY(bucket_sort());
+                PFQ_TRY(setup_verify());
+                PFQ_TRY(tile_stage());
+                if (block_mode) PFQ_TRY(finish_blocks());
+                else PFQ_TRY(finish_pairs());
             } else {
-                PFQ_TRY(classify_groups(false));
+                PFQ_TRY(frontier(false));
                 if (ev) HIP_TRY(hipEventRecord(ev[1], st));
             }
             HIP_TRY(hipGetLastError());
@@ -1433,7 +1150,367 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
             HIP_TRY(hipEventRecord(t.hint_ev, st));
             t.hint_reads = n_reads;
         }
-        if (!want_hits) return PFQ_OK;
+        return PFQ_OK;
+    }
+
+    // deferred-pair buffer, bucket histograms, probe records, miss words; block tables on first use
+    int setup_pairs() {
+        t.last_sub_log2 = sub_log2;
+        cnt = t.d_bucket.p;
+        off = cnt + nb;
+        cur = off + nb + 1;
+        a.pairs = t.d_pairs.p;
+        a.pair_cap = t.leaf_cap;  // whole reservations only (PAIR_CHUNK = 32)
+        a.pair_cursor = t.d_cursors.p + 1;
+        a.bucket_cnt = cnt;
+        a.sub_log2 = sub_log2;
+        recs = recs_possible ? t.d_recs.p : nullptr;
+        a.recs = recs;
+        a.rec_cap = recs ? t.d_recs.n : 0;
+        cntw = offw = curw = nullptr;
+        if (counts_mode && !block_mode) {
+            cntw = t.d_bucket_w.p;
+            offw = cntw + nb;
+            curw = offw + nb + 1;
+            HIP_TRY(hipMemsetAsync(t.d_miss_words.p, 0, miss_cap * 8, st));
+            HIP_TRY(hipMemsetAsync(cntw, 0, nb * 4, st));
+            a.bucket_words = cntw;
+            a.miss_cursor = t.d_cursors.p + 5;
+            a.miss_cap = miss_cap;
+        }
+        n_slices = 1;
+        uint64_t slice_target = SLICE_TARGET_BYTES;
+        if (kn.slice_kb > 0) slice_target = (uint64_t)kn.slice_kb << 10;
+        while (n_slices < 8 && (t.n_words * 8 + n_slices - 1) / n_slices > slice_target) n_slices <<= 1;
+        t.last_slices = n_slices;
+        HIP_TRY(hipMemsetAsync(cnt, 0, nb * 4, st));
+        HIP_TRY(hipMemsetAsync(t.d_fail.p, 0, t.d_fail.n * 4, st));
+        if (with_guards) HIP_TRY(hipMemsetAsync(t.d_gfail.p, 0, t.d_gfail.n * 4, st));
+        HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 128 * 4, st));
+        a.batch_tails = (recs && !counts_mode && kn.no_tail_batch <= 0) ? 1u : 0u;
+        a.block_pairs = block_mode ? 1u : 0u;
+        a.screen_recs = kn.screen_recs >= 0 ? (uint32_t)(kn.screen_recs != 0) : 1u;
+        if (block_mode) {
+            if (!t.tables_valid) {  // (the leaf set changed, or first use)
+                pfq::launch_block_tables(t.d_bits.p, t.n_words, t.d_col_row.p, (uint32_t)nl, t.d_T.p, st);
+                t.tables_valid = true;
+            }
+            HIP_TRY(hipMemsetAsync(t.d_failb.p, 0, t.d_failb.n, st));
+        }
+        return PFQ_OK;
+    }
+    // guard columns of the deferred pairs (pairs of their own), the records of the last windows
+    int guards_and_tails() {
+        ga = pfq::GuardArgs{};
+        if (with_guards && !block_mode) {  // every guard of a deferred pair's leaf becomes a pair of its own (second region of the buffer)
+            ga.pairs = t.d_pairs.p + t.leaf_cap;
+            ga.cap = t.guard_cap;
+            ga.cursor = t.d_cursors.p + 8;
+            ga.slot0 = (uint32_t)t.leaf_cap;
+            ga.owner = t.d_owner.p;
+            ga.gfail = t.d_gfail.p;
+            pfq::launch_expand_guards(a, ga, 2048, st);
+        }
+        if (a.batch_tails) pfq::launch_tail_records(a, 2048, st);
+        if (ev) HIP_TRY(hipEventRecord(ev[1], st));
+        return PFQ_OK;
+    }
+    // counting sort of the pairs by column (block mode: by (block, candidate mask))
+    int bucket_sort() {
+        pfq::launch_bucket_scan(cnt, off, cur, (uint32_t)nb, st);
+        if (counts_mode && !block_mode) pfq::launch_bucket_scan(cntw, offw, curw, (uint32_t)nb, st);
+        pfq::launch_bucket_scatter(t.d_pairs.p, t.d_cursors.p + 1, a.pair_cap, off, cur, sub_log2, t.d_sorted.p,
+                                   recs ? t.d_meta.p : nullptr, d_off, block_mode ? nullptr : t.d_col_row.p, offw, curw,
+                                   (counts_mode && !block_mode) ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
+                                   (with_guards && !block_mode) ? t.d_owner.p : nullptr,
+                                   (with_guards && !block_mode) ? t.d_owner_sorted.p : nullptr,
+                                   block_mode ? 2u : 0u, 1024, st);
+        if (with_guards && !block_mode)
+            pfq::launch_bucket_scatter(ga.pairs, ga.cursor, ga.cap, off, cur, sub_log2, t.d_sorted.p,
+                                       recs ? t.d_meta.p : nullptr, d_off, t.d_col_row.p, offw, curw,
+                                       counts_mode ? t.d_miss_pos.p : nullptr, (uint32_t)t.kmer_size,
+                                       t.d_owner.p + t.leaf_cap, t.d_owner_sorted.p, 0u, 256, st);
+        if (ev) HIP_TRY(hipEventRecord(ev[2], st));
+        return PFQ_OK;
+    }
+    int setup_verify() {
+        v = pfq::VerifyArgs{};
+        v.hp = t.hp;
+        v.seq = d_seq;
+        v.off = d_off;
+        v.bits = t.d_bits.p;
+        v.col_row = t.d_col_row.p;
+        v.n_words = t.n_words;
+        v.sorted = t.d_sorted.p;
+        v.n_pairs_ptr = off + nb;
+        v.fail = t.d_fail.p;
+        v.recs = recs;
+        v.miss_words = (counts_mode && !block_mode) ? t.d_miss_words.p : nullptr;
+        v.miss_pos = (counts_mode && !block_mode) ? t.d_miss_pos.p : nullptr;
+        v.meta = t.d_meta.p;
+        v.n_slices = n_slices;
+        uint64_t sb = (t.n_words * 64 + n_slices - 1) / n_slices;
+        v.slice_bits = (uint32_t)((sb + 63) & ~63ull);
+        v.queue = t.d_queue.p;
+        // window of pairs in flight per slice = (blocks/8)*(8/n_slices)*4*chunk: about one leaf bucket
+        vblocks = 512;
+        v.chunk = 1;
+        if (kn.verify_blocks >= 0) vblocks = std::max(8, (int)kn.verify_blocks & ~7);
+        if (kn.verify_chunk >= 0) v.chunk = (uint32_t)std::max(1, (int)kn.verify_chunk);
+        v.n_sub = 8;
+        if (kn.verify_sub >= 0) v.n_sub = (uint32_t)std::min(16, std::max(1, (int)kn.verify_sub));
+        vthreads = 512;
+        if (kn.verify_threads >= 0) vthreads = std::min(1024, std::max(64, (int)kn.verify_threads & ~63));
+        if (!recs) { vthreads = 256; vblocks = 1024; v.chunk = 4; }  // re-hash fallback kernel: 4-wave blocks
+        return PFQ_OK;
+    }
+    int tile_stage() {
+        // LDS-tile certificates: every probe binned by (leaf chunk, 128 KiB filter tile), tiles tested out of LDS;
+        // k_verify_rec then only sees the pairs that could not be binned
+        // (thresholds < 1: entries name k-mers, tiles are half the size — pfq::TILE_LOG2_COUNTS)
+        const uint32_t tile_log2 = block_mode ? pfq::TILE_LOG2_BLOCK : (counts_mode ? pfq::TILE_LOG2_COUNTS : pfq::TILE_LOG2);
+        const uint32_t n_tiles = (uint32_t)((t.n_words * 64 + (1ull << tile_log2) - 1) >> tile_log2);
+        const uint32_t chunk_log2 = pfq::CHUNK_PAIRS_LOG2;
+        // Thresholds < 1: the tile passes leave the k-mers that are not contained in per-chunk miss bitmaps; k_verify_rec
+        // only sees what could not be binned.  (PFQ_TILE_COUNTS=0: record kernel only.)  Results do not depend on the choice.
+        bool tile_counts = true;
+        if (kn.tile_counts >= 0) tile_counts = kn.tile_counts != 0;
+        bool tile_mode = recs && (!counts_mode || tile_counts) && (block_mode || n_tiles < 256);
+        if (kn.tile >= 0) tile_mode = tile_mode && kn.tile != 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = 0; }
+        uint64_t tile_budget = std::min<uint64_t>(64ull << 30, (uint64_t)((double)(mem_free + t.d_entries.bytes()) * 0.8));
+        if (kn.tile_gb >= 0) tile_budget = (uint64_t)kn.tile_gb << 30;
+        t.last_tile_mode = 0;
+        if (tile_mode) {
+            // every read may survive with one candidate: (bases - (k-1) per read) * hashes * 1.125 + slack per bucket
+            const uint64_t max_chunks = nc + ((t.leaf_cap + t.guard_cap) >> chunk_log2) + 2;
+            uint64_t want = (uint64_t)((double)total_bytes * t.num_hashes * 1.13 * std::max(1.0, t.pairs_per_read)) +
+                            max_chunks * n_tiles * 544ull;
+            if (want * 4 > tile_budget) want = tile_budget / 4;
+            if (kn.tile_entries >= 0) want = std::max<uint64_t>(1, (uint64_t)kn.tile_entries);  // tests: force passes
+            // thresholds < 1: one miss byte per k-mer of every pair the recent calls make expect (chunks that find no room
+            // take the fallback), the rounds' positions, the pairs' positions
+            // (block mode: 8 bytes per k-mer, one per leaf of the block; chunk offsets are in 16-byte units)
+            const uint64_t kmiss_cap = counts_mode ? std::min<uint64_t>(((uint64_t)((double)total_bytes * std::max(1.0, 1.3 * t.pairs_per_read)) + 16 * max_chunks + 64) * (block_mode ? 8u : 1u),
+                                                                            block_mode ? (48ull << 30) : 0xfffffff0ull) & ~15ull : 0;
+            bool ok = soft_ensure(t.d_entries, want) && soft_ensure(t.d_pair_chunk, t.d_pairs.n) && soft_ensure(t.d_flag_list, t.d_pairs.n) &&
+                      soft_ensure(t.d_leaf_chunk0, nc + 1) && soft_ensure(t.d_chunks, max_chunks) && soft_ensure(t.d_gfill, max_chunks * n_tiles) && soft_ensure(t.d_binq, 256);
+            if (ok && counts_mode)
+                ok = soft_ensure(t.d_kmiss, kmiss_cap) && soft_ensure(t.d_round_k0, max_chunks * pfq::MAX_ROUNDS) &&
+                     soft_ensure(t.d_n_rounds, max_chunks) && soft_ensure(t.d_pair_kpos, t.d_pairs.n);
+            if (ok && counts_mode && block_mode) ok = soft_ensure(t.d_kall, (kmiss_cap >> 3) + 64);
+            if (!ok) {
+                tile_mode = false;  // not enough HBM for the probe buckets: stay with the record kernel
+            } else {
+                HIP_TRY(hipMemsetAsync(t.d_gfill.p, 0, max_chunks * n_tiles * 4, st));
+                HIP_TRY(hipMemsetAsync(t.d_binq.p, 0, 256 * 4, st));
+                pfq::TileArgs ta{};
+                ta.hp = t.hp;
+                ta.bits = t.d_bits.p;
+                ta.n_words = t.n_words;
+                ta.chunk_log2 = chunk_log2;
+                if (block_mode) {  // the "filter" of a bucket is its block's table: n_words * 64 bytes
+                    ta.blocks = 1;
+                    if (counts_mode) ta.kall = t.d_kall.p;  // (buckets by (block, mask); the passes' columns are the blocks)
+                    ta.bits = reinterpret_cast<const uint64_t *>(t.d_T.p);
+                    ta.n_words = t.n_words * 8;
+                    ta.failb = t.d_failb.p;
+                }
+                ta.recs = recs;
+                ta.meta = t.d_meta.p;
+                ta.col_row = t.d_col_row.p;
+                ta.bucket_off = off;
+                ta.sub_log2 = sub_log2;
+                ta.n_leaves = (uint32_t)(block_mode ? n_blocks : nc);  // (columns of the passes: blocks, whatever the buckets)
+                ta.n_tiles = n_tiles;
+                ta.chunks = t.d_chunks.p;
+                ta.max_chunks = (uint32_t)max_chunks;
+                ta.leaf_chunk0 = t.d_leaf_chunk0.p;
+                ta.pair_chunk = t.d_pair_chunk.p;
+                ta.n_chunks = reinterpret_cast<unsigned int *>(t.d_cursors.p + 3);
+                ta.n_flagged = reinterpret_cast<unsigned int *>(t.d_cursors.p + 3) + 1;
+                ta.flag_list = t.d_flag_list.p;
+                ta.flag_cap = (uint32_t)std::min<uint64_t>(t.d_flag_list.n, 0xffffffffu);
+                ta.entry_cursor = t.d_cursors.p + 2;
+                // (a multiple of 32 entries: buckets then start on 128-byte boundaries, k_tile_test reads them 16 bytes at a time)
+                ta.entry_cap = std::min<uint64_t>(want, t.d_entries.n) & ~31ull;  // (the buffer only grows; the budget of this call is `want`)
+                ta.entries = t.d_entries.p;
+                ta.gfill = t.d_gfill.p;
+                ta.fail = t.d_fail.p;
+                ta.n_pairs_ptr = off + nb;
+                if (counts_mode) {
+                    ta.counts = 1;
+                    ta.threshold = threshold;
+                    ta.kmiss = t.d_kmiss.p;
+                    ta.kmiss_cap = kmiss_cap;
+                    ta.kmiss_used = t.d_cursors.p + 9;
+                    ta.round_k0 = t.d_round_k0.p;
+                    ta.n_rounds = t.d_n_rounds.p;
+                    ta.pair_kpos = t.d_pair_kpos.p;
+                    HIP_TRY(hipMemsetAsync(t.d_n_rounds.p, 0, max_chunks * 4, st));
+                }
+                int bin_blocks = 512, test_blocks = 512;
+                if (kn.bin_blocks >= 0) bin_blocks = std::max(1, (int)kn.bin_blocks);
+                if (kn.test_blocks >= 0) test_blocks = std::max(1, (int)kn.test_blocks);
+                ta.bin_shape = kn.bin_narrow > 0 ? (uint32_t)kn.bin_narrow : (kn.bin_wide > 0 ? 2u : 0u);
+                ta.debug = kn.bin_debug > 0 ? (uint32_t)kn.bin_debug : 0u;
+                pfq::launch_tile_plan(ta, st);
+                // The probe buckets of all pairs may exceed the buffer (reads that pass many leaves): the plan
+                // spreads the chunks over passes that reuse it.  Their number is known on the device only; as
+                // many passes as the previous call needed are launched without waiting, and chunks of later
+                // passes (if any) are certified by the record kernel below — exact either way.
+                uint64_t n_passes = std::min<uint64_t>(std::max<uint64_t>(1, t.passes_hint), 256);  // (more: the record kernel takes the rest)
+                if (block_mode) {  // the fallback of block mode is slow: wait for the plan and launch every pass it needs
+                    HIP_TRY(hipMemcpyAsync(t.h_pair_cursor + 5, t.d_cursors.p + 2, 8, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    n_passes = ta.entry_cap ? std::min<uint64_t>(std::max<uint64_t>(1, (t.h_pair_cursor[5] + ta.entry_cap - 1) / ta.entry_cap), 256) : 1;
+                }
+                for (uint64_t p = 0; p < n_passes; ++p) {
+                    ta.pass = (uint32_t)p;
+                    ta.bin_queue = t.d_binq.p + p;
+                    pfq::launch_tile_bin(ta, bin_blocks, st);
+                    if (p == 0 && ev) HIP_TRY(hipEventRecord(ev[3], st));
+                    pfq::launch_tile_test(ta, test_blocks, st);
+                }
+                v.pair_chunk = t.d_pair_chunk.p;
+                v.chunks = t.d_chunks.p;
+                v.entry_cursor = t.d_cursors.p + 2;
+                v.entry_cap = ta.entry_cap;
+                v.launched_passes = (uint32_t)n_passes;
+                if (counts_mode && !block_mode) {  // binned pairs whose prefix of k-mers leaves them undecided go to the record kernel
+                    pfq::FinalizeArgs pf{};
+                    pf.hp = t.hp;
+                    pf.threshold = threshold;
+                    pf.fail = t.d_fail.p;
+                    pf.kmiss = t.d_kmiss.p;
+                    pf.pair_kpos = t.d_pair_kpos.p;
+                    pf.pair_chunk = t.d_pair_chunk.p;
+                    pf.chunks = t.d_chunks.p;
+                    pf.launched_passes = (uint32_t)n_passes;
+                    pfq::launch_prefix_open(pf, t.d_meta.p, off + nb, t.d_fail.p, st);
+                }
+                t.hint_entry_cap = ta.entry_cap;
+                t.last_passes = (uint32_t)std::max<uint64_t>(n_passes, 1);
+                if (ev) HIP_TRY(hipEventRecord(ev[4], st));
+                v.only_flagged = 1;
+                v.n_flagged = ta.n_flagged;
+                v.flag_list = t.d_flag_list.p;
+                v.flag_cap = ta.flag_cap;
+                t.last_tile_mode = 1;
+            }
+        }
+        if (ev && !t.last_tile_mode) {
+            HIP_TRY(hipEventRecord(ev[3], st));
+            HIP_TRY(hipEventRecord(ev[4], st));
+        }
+        return PFQ_OK;
+    }
+    int finish_blocks() {
+        // what the passes did not bin (overflows, no room, or no passes at all) is certified leaf by leaf against S
+        a.S = t.d_S.p;
+        a.col0 = 0;
+        a.n_leaves = (uint32_t)std::min<size_t>(2048, nl);
+        if (counts_mode && t.last_tile_mode) {  // the miss bytes of the binned pairs decide their candidates
+            pfq::FinalizeArgs cf{};
+            cf.hp = t.hp;
+            cf.off = d_off;
+            cf.sorted = t.d_sorted.p;
+            cf.threshold = threshold;
+            cf.fail = t.d_fail.p;
+            cf.kmiss = t.d_kmiss.p;
+            cf.kall = t.d_kall.p;
+            cf.pair_kpos = t.d_pair_kpos.p;
+            cf.pair_chunk = t.d_pair_chunk.p;
+            cf.chunks = t.d_chunks.p;
+            cf.launched_passes = v.launched_passes;
+            pfq::launch_block_count(cf, off + nb, t.d_failb.p, st);
+        }
+        pfq::launch_block_fallback(a, t.d_sorted.p, off + nb, t.d_fail.p, t.d_failb.p, t.d_pair_chunk.p,
+                                   t.last_tile_mode ? t.d_chunks.p : nullptr, v.launched_passes,
+                                   t.last_tile_mode ? v.n_flagged : nullptr, t.last_tile_mode ? v.flag_list : nullptr, v.flag_cap, st);
+        // ancestors that are not provably supersets must pass too (query.rs:119-141): the guards of every candidate
+        // that is still standing
+        if (with_guards) pfq::launch_block_guards(a, t.d_sorted.p, off + nb, t.d_failb.p, st);
+        if (ev) HIP_TRY(hipEventRecord(ev[5], st));
+        pfq::FinalizeArgs f{};
+        f.hp = t.hp;
+        f.off = d_off;
+        f.sorted = t.d_sorted.p;
+        f.bucket_off = off;
+        f.sub_log2 = sub_log2;
+        f.threshold = threshold;
+        f.counts = t.d_counts.p;
+        f.hit_pairs = a.hit_pairs;
+        f.hit_cap = hit_cap;
+        f.hit_cursor = t.d_cursors.p;
+        f.stats = t.d_stats.p;
+        f.failb = t.d_failb.p;
+        f.c0 = 0;
+        f.c1 = (uint32_t)nc;
+        pfq::launch_finalize(f, st);
+        if (ev) HIP_TRY(hipEventRecord(ev[6], st));
+        t.last_block_mode = 1;
+        if (t.last_tile_mode) t.last_tile_mode = 2;
+        t.hint_counts = false;
+        return PFQ_OK;
+    }
+    int finish_pairs() {
+        if (v.only_flagged == 1 && counts_mode) {
+            // thresholds < 1: the list becomes every pair the tile passes left open (a k-mer missing, or not binned)
+            unsigned int *n_open = reinterpret_cast<unsigned int *>(t.d_cursors.p + 7);
+            pfq::launch_collect_open(t.d_fail.p, off + nb, t.d_flag_list.p, v.flag_cap, n_open, st);
+            v.n_flagged = n_open;
+        }
+        pfq::launch_verify(v, vblocks, vthreads, st);
+        if (v.only_flagged == 1) {  // many flagged pairs (no room for their probe buckets): walk all pairs in leaf order instead
+            v.only_flagged = 2;
+            if (counts_mode) v.chunk = 8;  // (the walk pulls an item per 64 pairs, not per 8)
+            pfq::launch_verify(v, vblocks, vthreads, st);
+        }
+        if (ev) HIP_TRY(hipEventRecord(ev[5], st));
+        pfq::FinalizeArgs f{};
+        f.hp = t.hp;
+        f.off = d_off;
+        f.sorted = t.d_sorted.p;
+        f.bucket_off = off;
+        f.sub_log2 = sub_log2;
+        f.fail = t.d_fail.p;
+        f.miss_words = v.miss_words;
+        f.miss_pos = v.miss_pos;
+        f.threshold = threshold;
+        f.counts = t.d_counts.p;
+        f.hit_pairs = a.hit_pairs;
+        f.hit_cap = hit_cap;
+        f.hit_cursor = t.d_cursors.p;
+        f.stats = t.d_stats.p;
+        f.n_dirty = t.d_cursors.p + 6;
+        if (counts_mode && t.last_tile_mode) {  // miss bits of the binned pairs: in their chunks' bitmaps
+            f.kmiss = t.d_kmiss.p;
+            f.pair_kpos = t.d_pair_kpos.p;
+            f.pair_chunk = t.d_pair_chunk.p;
+            f.chunks = t.d_chunks.p;
+            f.launched_passes = v.launched_passes;
+        }
+        f.owner_sorted = with_guards ? t.d_owner_sorted.p : nullptr;
+        f.gfail = with_guards ? t.d_gfail.p : nullptr;
+        t.hint_counts = counts_mode;
+        if (with_guards) {  // the guard columns first: a guard that does not pass marks its leaf pair
+            f.c0 = (uint32_t)nl;
+            f.c1 = (uint32_t)nc;
+            f.guards = 1;
+            pfq::launch_finalize(f, st);
+        }
+        f.c0 = 0;
+        f.c1 = (uint32_t)nl;
+        f.guards = 0;
+        pfq::launch_finalize(f, st);
+        if (ev) HIP_TRY(hipEventRecord(ev[6], st));
+        return PFQ_OK;
+    }
+
+    // PFQ_WANT_HITS: the per-read hit lists of this attempt; done = false: the hit buffer was too small, run again
+    int read_hits(bool &done) {
+        done = true;
         HIP_TRY(hipStreamSynchronize(st));
         unsigned long long cursors[2] = {0, 0};
         HIP_TRY(hipMemcpy(cursors, t.d_cursors.p, 16, hipMemcpyDeviceToHost));
@@ -1485,8 +1562,27 @@ int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint6
         if (nl) HIP_TRY(hipMemcpy(t.d_counts.p, t.d_counts_snapshot.p, nl * 8, hipMemcpyDeviceToDevice));
         HIP_TRY(t.d_hit_pairs.ensure(cursors[0] + 1024));
         hit_cap = t.d_hit_pairs.n;
+        done = false;
+        return PFQ_OK;
     }
-    return fail(PFQ_ERR_DEVICE, "hit buffer overflow persisted");
+
+    int run() {
+        for (int attempt_no = 0; attempt_no < 2; ++attempt_no) {
+            PFQ_TRY(attempt(attempt_no));
+            if (!want_hits) return PFQ_OK;
+            bool done = false;
+            PFQ_TRY(read_hits(done));
+            if (done) return PFQ_OK;
+        }
+        return fail(PFQ_ERR_DEVICE, "hit buffer overflow persisted");
+    }
+};
+
+int query_device(pfq_tree &t, const uint8_t *d_seq, const uint64_t *d_off, uint64_t n_reads, uint64_t total_bytes,
+                 float threshold, uint32_t flags, hipStream_t st, pfq_hits *hits) {
+    QueryRun q(t, d_seq, d_off, n_reads, total_bytes, threshold, flags, st, hits);
+    PFQ_TRY(q.plan());
+    return q.run();
 }
 
 // Reduce a whole tree to subtree shard `index` of the depth-`depth` frontier (pfq_tree_open_subtree): the shard's node,
