@@ -2,6 +2,7 @@
 level of internal nodes first and every group of leaf columns only sees the reads with a live ancestor there — the
 device's form of the reference descending with the survivors only (query.rs:113-141).  Through the C ABI, against the
 CPU oracle's full DFS; bit-exact, and equal to the flat frontier (PFQ_COARSE=0) on the same inputs."""
+import os
 import sys
 
 import numpy as np
@@ -176,4 +177,61 @@ def test_two_level_with_colliding_internal_names(gpu, tmp_path):
         for path in (0, 1):
             st = check_query(gt, ot, reads, thr, path=path)
             assert st.coarse_cols > 0 and st.path == path
+    gt.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# randomized: tree shape, size, filter geometry, fill of the coarse level, reads, thresholds, paths and layout knobs
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [int(os.environ.get("PFQ_TWO_LEVEL_SEED0", "0")) + i
+                                  for i in range(int(os.environ.get("PFQ_TWO_LEVEL_SEEDS", "6")))])   # (soak runs: more seeds)
+def test_two_level_randomized(gpu, tmp_path, seed):
+    """Every draw goes through the same comparison with the oracle's DFS (per-leaf counts and every per-read hit set): 2100 to
+    4200 leaves, balanced or random shapes with a caterpillar, filters from nearly empty to half full at the coarse level,
+    related genomes (a read is a candidate in several leaf groups), short and long reads, and a random layout knob."""
+    rng = np.random.default_rng(77000 + seed)
+    n_genomes = int(rng.choice([2100, 2600, 3300, 4200]))
+    k = int(rng.choice([15, 20, 21, 31]))
+    h = int(rng.choice([3, 5, 10, 17]))
+    nbits = int(rng.choice([4099, 16381, 65521, 262147]))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def dna(n):
+        return bytes(rng.choice(acgt, int(n)).astype(np.uint8))
+
+    base = [dna(rng.integers(k + 40, 420)) for _ in range(max(2, n_genomes // int(rng.choice([1, 1, 4, 16]))))]
+    genomes = []
+    for i in range(n_genomes):
+        g = bytearray(base[int(rng.integers(0, len(base)))])
+        for _ in range(int(rng.integers(0, 5))):
+            g[int(rng.integers(0, len(g)))] = ord("ACGT"[int(rng.integers(0, 4))])
+        genomes.append(bytes(g))
+    for i in range(3):                                          # a few genomes long enough for reads of >= 256 k-mers
+        genomes[int(rng.integers(0, n_genomes))] = dna(700)
+    if rng.random() < 0.5:
+        ot, ids = oracle_tree(genomes, k, nbits, h)
+        gt = gpu_tree(genomes, ids, k, nbits, h)
+    else:
+        ot, ids = _random_shape_tree(genomes, k, nbits, h, skew=float(rng.choice([0.5, 0.9])), chain=int(rng.choice([0, 40, 300])))
+        d = str(tmp_path / "db")
+        fmt.write_db(ot, d)
+        gt = BloomTree.load(d)
+    reads = []
+    for _ in range(int(rng.integers(300, 700))):
+        src = genomes[int(rng.integers(0, n_genomes))]
+        L = int(min(len(src), rng.choice([k, k + 1, 100, 150, 151, 300, 700])))
+        o = int(rng.integers(0, len(src) - L + 1))
+        r = bytearray(src[o:o + L])
+        for _ in range(int(rng.choice([0, 0, 1, 3]))):
+            r[int(rng.integers(0, L))] = ord("ACGTN"[int(rng.integers(0, 5))])
+        reads.append(bytes(r) if rng.random() < 0.5 else orc.revcomp(bytes(r)))
+    reads += [dna(rng.integers(0, 300)) for _ in range(150)] + [b"", dna(k - 1)]
+    knob = [None, ("PFQ_GROUP_LOG2", "11"), ("PFQ_COARSE_COLS", "2048"), ("PFQ_COARSE_COLS", "512"), ("PFQ_COARSE_PROBES", "2"),
+            ("PFQ_BLOCK", "1"), ("PFQ_TILE_COUNTS", "0"), ("PFQ_COARSE", "1")][int(rng.integers(0, 8))]
+    if knob:
+        gt.set_option(*knob)
+    for thr in (1.0, float(rng.choice([0.05, 0.3, 0.5, 0.9])), float(rng.choice([0.0, 0.2, 0.75, 0.999, 1.5]))):
+        for path in (1, 0):
+            st = check_query(gt, ot, reads, thr, path=path)
+            assert st.leaf_groups >= 2, (seed, st.leaf_groups)
     gt.close()
