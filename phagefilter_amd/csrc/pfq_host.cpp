@@ -1187,7 +1187,14 @@ struct QueryRun {
         HIP_TRY(hipMemsetAsync(t.d_fail.p, 0, t.d_fail.n * 4, st));
         if (with_guards) HIP_TRY(hipMemsetAsync(t.d_gfail.p, 0, t.d_gfail.n * 4, st));
         HIP_TRY(hipMemsetAsync(t.d_queue.p, 0, 128 * 4, st));
-        a.batch_tails = (recs && !counts_mode && kn.no_tail_batch <= 0) ? 1u : 0u;
+        // last windows of few k-mers are hashed several reads per pass afterwards: of up to 16 k-mers, or of up to 32 when the
+        // reads' (average) length makes such tails — 100 bp reads at k = 20 have 64 + 17 k-mers
+        a.batch_tails = 0;
+        if (recs && !counts_mode && kn.no_tail_batch <= 0) {
+            const uint64_t avg_len = n_reads ? total_bytes / n_reads : 0;
+            const uint64_t tl = avg_len >= t.kmer_size ? ((avg_len - t.kmer_size + 1) & 63u) : 0;
+            a.batch_tails = (tl > 16 && tl <= 32) ? 32u : 16u;
+        }
         a.block_pairs = block_mode ? 1u : 0u;
         a.screen_recs = kn.screen_recs >= 0 ? (uint32_t)(kn.screen_recs != 0) : 1u;
         if (block_mode) {

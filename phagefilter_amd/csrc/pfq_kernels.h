@@ -72,7 +72,7 @@ struct QueryArgs {
     uint64_t rec_cap;            // entries in recs (reads whose records would not fit are certified inline)
     uint32_t *long_list;         // thresholds < 1: reads of >= 256 k-mers, classified by a second launch (wider counters)
     unsigned int *n_long;
-    uint32_t batch_tails;        // theta == 1 with records: last windows of <= TAIL_KMERS k-mers are left to k_tail_records
+    uint32_t batch_tails;        // theta == 1 with records: last windows of <= batch_tails k-mers (0: none, 16 or 32) are left to k_tail_records
     uint32_t block_pairs;        // 1 (DEFER, theta == 1, no guard columns): defer (read, block of 8 leaves | candidate mask << 24)
     uint32_t screen_recs;        // thresholds < 1: the dense counting screen writes the probe records of the k-mers it hashes
     uint32_t screen_only;        // (launches without deferral) count the frontier's candidate leaves, certify nothing, count no read

@@ -601,10 +601,11 @@ __device__ __forceinline__ void dense_counts(uint32_t *fw, uint32_t *rw_, const 
     }
 }
 
-// A read's last window of records is made by k_tail_records when it holds at most TAIL_KMERS k-mers.
-__device__ __forceinline__ bool has_batched_tail(uint64_t n) {
+// A read's last window of records is made by k_tail_records when it holds at most tail_max k-mers (16: four reads per pass;
+// 32: two — the host asks for 32 when the reads' length makes such tails, e.g. 100 bp reads at k = 20: 81 = 64 + 17 k-mers).
+__device__ __forceinline__ bool has_batched_tail(uint64_t n, uint32_t tail_max) {
     const uint32_t tl = (uint32_t)(n & (WIN_KMERS - 1u));
-    return n > WIN_KMERS && n < (1ull << 32) && tl != 0 && tl <= TAIL_KMERS;
+    return n > WIN_KMERS && n < (1ull << 32) && tl != 0 && tl <= tail_max;
 }
 
 // ---- the classification kernel ---------------------------------------------------------------------------------------
@@ -732,7 +733,7 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
                         prepared = true;
                         // 150 bp reads at k = 20..23 have 128 + (1..3) k-mers: a third hashing pass for two or three
                         // k-mers.  Such last windows are left to k_tail_records (four reads per pass).
-                        const bool split_tail = a.batch_tails && has_batched_tail(rc.n);
+                        const bool split_tail = a.batch_tails && has_batched_tail(rc.n, a.batch_tails);
                         for (uint64_t base = n_done; base < rc.n; base += WIN_KMERS) {
                             uint32_t cnt = (uint32_t)((rc.n - base) < WIN_KMERS ? (rc.n - base) : WIN_KMERS);
                             if (split_tail && base + WIN_KMERS > rc.n) break;
@@ -1154,22 +1155,26 @@ void launch_expand_guards(const QueryArgs &a, const GuardArgs &ga, int blocks, h
     hipLaunchKernelGGL(k_expand_guards, dim3(blocks), dim3(256), 0, st, a, ga);
 }
 
-// Records of the last windows k_classify<DEFER> left out (has_batched_tail): one pass serves four deferred pairs,
-// lane = (pair j of four, k-mer t of up to TAIL_KMERS).  Walks the deferred-pair buffer; a read deferred for two leaves
-// gets its tail records written twice (same values).
+// Records of the last windows k_classify<DEFER> left out (has_batched_tail): one pass serves 64 / TAIL deferred pairs,
+// lane = (pair j, k-mer t of up to TAIL); the TAIL = 32 build takes the tails of 17 .. 32 k-mers, the TAIL = 16 build the
+// shorter ones.  Walks the deferred-pair buffer; a read deferred for two leaves gets its tail records written twice (same
+// values).
+template <uint32_t TAIL>
 __global__ void __launch_bounds__(256) k_tail_records(QueryArgs a) {
-    __shared__ uint32_t s_fw[WAVES_PER_BLOCK][4 * 96 / 4], s_rc[WAVES_PER_BLOCK][4 * 96 / 4];
+    constexpr uint32_t PAIRS = 64u / TAIL, STRIDE = 384u / PAIRS, LOADS = (TAIL + KMAX - 1u + TAIL - 1u) / TAIL;  // bytes per pair in LDS; byte loads per lane
+    static_assert(WIN_PAD + TAIL + KMAX - 1u + WIN_PAD <= STRIDE + WIN_PAD, "a tail's bytes fit its share of the LDS");
+    __shared__ uint32_t s_fw[WAVES_PER_BLOCK][4 * 96 / 4 + 4], s_rc[WAVES_PER_BLOCK][4 * 96 / 4 + 4];
     __shared__ uint8_t s_comp[256];
     fill_complement(s_comp);
     __syncthreads();
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, k = a.hp.k;
-    const uint32_t j = lane >> 4, t = lane & 15u;
+    const uint32_t j = lane / TAIL, t = lane % TAIL;
     unsigned long long n_slots = *a.pair_cursor;
     if (n_slots > a.pair_cap) n_slots = a.pair_cap;
     uint32_t *tfw = s_fw[wave], *trc = s_rc[wave];
     uint8_t *tfwd = reinterpret_cast<uint8_t *>(tfw), *trcb = reinterpret_cast<uint8_t *>(trc);
     const uint64_t gw = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave, nw = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
-    for (uint64_t s0 = gw * 4u; s0 < n_slots; s0 += nw * 4u) {
+    for (uint64_t s0 = gw * PAIRS; s0 < n_slots; s0 += nw * PAIRS) {
         const uint64_t slot = s0 + j;
         uint32_t r = 0xffffffffu;
         if (slot < n_slots) r = a.pairs[slot].x;
@@ -1179,23 +1184,24 @@ __global__ void __launch_bounds__(256) k_tail_records(QueryArgs a) {
             const uint64_t L = a.off[r + 1] - o0;
             n = (L >= k) ? (L - k + 1) : 0;
         }
-        const bool have = r != 0xffffffffu && has_batched_tail(n) && o0 + n <= a.rec_cap;
-        if (ballot64(have) == 0) continue;
         const uint32_t tl = (uint32_t)(n & (WIN_KMERS - 1u));
+        // (tails of up to 16 k-mers belong to the TAIL = 16 build, longer ones to the TAIL = 32 build)
+        const bool have = r != 0xffffffffu && has_batched_tail(n, a.batch_tails) && (TAIL == 16 ? tl <= 16u : tl > 16u) && o0 + n <= a.rec_cap;
+        if (ballot64(have) == 0) continue;
         const uint64_t base = n - tl;
-        const uint32_t W = have ? tl + k - 1u : 0u;  // <= TAIL_KMERS + KMAX - 1 = 79 bytes
-        const uint32_t mb = j * 96u + WIN_PAD;
+        const uint32_t W = have ? tl + k - 1u : 0u;  // <= TAIL + KMAX - 1 bytes
+        const uint32_t mb = j * STRIDE + WIN_PAD;
         const uint8_t *src = a.seq + (have ? o0 + base : 0ull);
         __builtin_amdgcn_wave_barrier();
-        uint8_t b[5];
+        uint8_t b[LOADS];
 #pragma unroll
-        for (uint32_t u = 0; u < 5; ++u) {
-            const uint32_t idx = 16u * u + t;
+        for (uint32_t u = 0; u < LOADS; ++u) {
+            const uint32_t idx = TAIL * u + t;
             b[u] = src[idx < W ? idx : 0u];
         }
 #pragma unroll
-        for (uint32_t u = 0; u < 5; ++u) {
-            const uint32_t idx = 16u * u + t;
+        for (uint32_t u = 0; u < LOADS; ++u) {
+            const uint32_t idx = TAIL * u + t;
             if (idx < W) {
                 tfwd[mb + idx] = b[u];
                 trcb[mb + (W - 1u - idx)] = s_comp[b[u]];
@@ -1210,7 +1216,8 @@ __global__ void __launch_bounds__(256) k_tail_records(QueryArgs a) {
     }
 }
 void launch_tail_records(const QueryArgs &a, int blocks, hipStream_t st) {
-    hipLaunchKernelGGL(k_tail_records, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_tail_records<16>, dim3(blocks), dim3(256), 0, st, a);
+    if (a.batch_tails > 16u) hipLaunchKernelGGL(k_tail_records<32>, dim3(blocks), dim3(256), 0, st, a);
 }
 
 // ---- bucketing of deferred (read, leaf) pairs by leaf --------------------------------------------------------------
