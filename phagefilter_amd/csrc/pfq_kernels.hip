@@ -992,7 +992,63 @@ __global__ void __launch_bounds__(256, 2) k_coarse(QueryArgs a, CoarseArgs ca) {
         }
         emit(r, nullptr);
     };
+    // The survivors of a dense group (up to 64 / lanes-per-read reads), appended together: lane jj < n_rd owns read jj, walks
+    // its frontier words (rotated by the lane: no LDS bank is hit twice) for the leaf groups below its live columns; then per
+    // group ONE step appends all its reads — slots from the wave's reservation, a new one when it runs over.  (One read at a
+    // time, each with its own LDS round trips, the appends cost more than the screens: 8.5 survivors per pass at theta = 1.)
+    auto emit_batch = [&](uint32_t survive, uint32_t rid_lo, uint32_t lanes_log2) {
+        const uint32_t n_rd = 64u >> lanes_log2;
+        const bool mine = lane < n_rd && ((survive >> lane) & 1u);
+        const uint32_t my_rid = (uint32_t)__shfl((int)rid_lo, (int)((lane < n_rd ? lane : 0u) << lanes_log2));
+        uint64_t gset = 0;
+        if (mine) {
+            const uint32_t *pre = dlds.live[wave] + lane * rw;
+            for (uint32_t i = 0; i < rw; ++i) {
+                const uint32_t wi = (i + lane) & (rw - 1u);
+                uint32_t w = pre[wi];
+                while (w) {
+                    const uint32_t b = (uint32_t)__ffs((int)w) - 1u;
+                    w &= w - 1u;
+                    const uint32_t rng = ca.cgrp[wi * 32u + b], lo = rng & 0xffffu, hi = rng >> 16;
+                    gset |= (hi >= 63u ? ~0ull : ((1ull << (hi + 1u)) - 1ull)) & ~((1ull << lo) - 1ull);
+                }
+            }
+        }
+        uint64_t present = gset;
+        for (int d = 32; d > 0; d >>= 1) present |= __shfl_xor(present, d);
+        present = bcast_u64(present, 0);
+        while (present) {
+            const uint32_t g = (uint32_t)__ffsll((unsigned long long)present) - 1u;
+            present &= present - 1ull;
+            const bool in = mine && ((gset >> g) & 1ull);
+            const uint64_t m = ballot64(in);
+            const uint32_t c = (uint32_t)__popcll(m), rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t used = s_lused[wave][g], base_old = s_lbase[wave][g];
+            uint32_t base_new = 0;
+            if (used + c > PAIR_CHUNK) {  // (wave-uniform) the reservation runs over: a new one takes the rest
+                if (lane == 0) base_new = atomicAdd(&ca.cursors[g], PAIR_CHUNK);
+                base_new = bcast_u32(base_new, 0);
+            }
+            if (in) {
+                const uint32_t p = used + rank;
+                ca.lists[(uint64_t)g * ca.list_cap + (p < PAIR_CHUNK ? base_old + p : base_new + (p - PAIR_CHUNK))] = my_rid;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                if (used + c > PAIR_CHUNK) {
+                    s_lbase[wave][g] = base_new;
+                    s_lused[wave][g] = used + c - PAIR_CHUNK;
+                } else s_lused[wave][g] = used + c;
+            }
+            st_listed += c;
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
     auto finish_group = [&](uint32_t survive, uint32_t irregular, uint32_t rid_lo, uint32_t lanes_log2) {
+        if (!COUNTS) {
+            if (survive) emit_batch(survive, rid_lo, lanes_log2);
+            survive = 0;
+        }
         while (survive) {
             const uint32_t jj = (uint32_t)__ffs((int)survive) - 1u;
             survive &= survive - 1u;
