@@ -82,7 +82,7 @@ struct Knobs {
     long long record_gb = -1, tile_gb = -1, tile_entries = -1, slice_kb = -1;
     long long verify_blocks = -1, verify_chunk = -1, verify_sub = -1, verify_threads = -1, bin_blocks = -1, test_blocks = -1;
     long long tile = -1, tile_counts = -1, no_tail_batch = -1, bin_narrow = -1, bin_wide = -1, bin_debug = -1, block = -1;
-    long long coarse = -1, coarse_cols = -1, coarse_probes = -1, group_log2 = -1, screen_recs = -1, coarse_min_leaves = -1;
+    long long coarse = -1, coarse_cols = -1, coarse_probes = -1, group_log2 = -1, screen_recs = -1, coarse_min_leaves = -1, greedy_host = -1;
 };
 struct KnobName {
     const char *name;
@@ -104,6 +104,7 @@ const KnobName KNOBS[] = {
     {"PFQ_COARSE", &Knobs::coarse},             {"PFQ_COARSE_COLS", &Knobs::coarse_cols},
     {"PFQ_COARSE_PROBES", &Knobs::coarse_probes}, {"PFQ_GROUP_LOG2", &Knobs::group_log2},
     {"PFQ_SCREEN_RECS", &Knobs::screen_recs},   {"PFQ_COARSE_MIN_LEAVES", &Knobs::coarse_min_leaves},
+    {"PFQ_GREEDY_HOST", &Knobs::greedy_host},
 };
 bool set_knob(Knobs &k, const char *name, const char *value) {
     for (const KnobName &kn : KNOBS)
@@ -2007,13 +2008,14 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
     }
     // the device's copy of the shape (all of it once; afterwards the kernel keeps it current)
     const size_t n_after = t.nodes.size() + 2;
-    if (!t.topo_on_device || t.d_topo.n < n_after) {
+    if (t.knobs.greedy_host > 0) HIP_TRY(t.d_dist.ensure(2 * (size_t)pfq::INSERT_STEP_BLOCKS));
+    else if (!t.topo_on_device || t.d_topo.n < n_after) {
         PFQ_TRY(sync_topology(t));
         HIP_TRY(hipDeviceSynchronize());
         const size_t cap = std::max<size_t>(n_after, 2 * t.d_topo.n + 1024);
         HIP_TRY(t.d_topo.ensure(cap));
         HIP_TRY(t.d_walk.ensure(4));
-        HIP_TRY(t.d_dist.ensure(4 * (size_t)pfq::GREEDY_MAX_BLOCKS));
+        HIP_TRY(t.d_dist.ensure(std::max<size_t>(4 * (size_t)pfq::GREEDY_MAX_BLOCKS, 2 * (size_t)pfq::INSERT_STEP_BLOCKS)));
         std::vector<pfq::TopoNode> h(t.nodes.size());
         for (size_t v = 0; v < h.size(); ++v) h[v] = pfq::TopoNode{t.nodes[v].left, t.nodes[v].right, t.nodes[v].filter, 0u};
         if (!h.empty()) HIP_TRY(hipMemcpy(t.d_topo.p, h.data(), h.size() * sizeof(pfq::TopoNode), hipMemcpyHostToDevice));
@@ -2048,6 +2050,66 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
     const int32_t nv = (int32_t)t.nodes.size();
     t.nodes.push_back(leaf);
     t.topology_dirty = true;
+    // PFQ_GREEDY_HOST=1: the descent level by level from the host (one launch and one read-back per level; no kernel with a
+    // grid barrier) — for devices that are shared with other work, where not every block of such a kernel stays resident
+    if (t.knobs.greedy_host > 0) {
+        PFQ_TRY(sync_topology(t));
+        t.topo_on_device = false;
+        if (t.root < 0 || nv == 0) {
+            t.root = nv;
+            --t.n_rows;  // (no internal node: its row is not used)
+            HIP_TRY(hipDeviceSynchronize());
+            return PFQ_OK;
+        }
+        std::vector<unsigned long long> part(2 * pfq::INSERT_STEP_BLOCKS);
+        int32_t cur = t.root, parent = -1;
+        bool went_right = false;
+        while (true) {
+            const Node &c = t.nodes[cur];
+            if (c.left >= 0 && c.right >= 0) {
+                pfq::launch_insert_step(t.d_bits.p, t.n_words, c.filter, new_row, t.nodes[c.left].filter, t.nodes[c.right].filter, t.d_dist.p, nullptr);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpy(part.data(), t.d_dist.p, part.size() * 8, hipMemcpyDeviceToHost));
+                unsigned long long d[2] = {0, 0};
+                for (uint32_t b = 0; b < pfq::INSERT_STEP_BLOCKS; ++b) {
+                    d[0] += part[2 * b];
+                    d[1] += part[2 * b + 1];
+                }
+                parent = cur;
+                went_right = d[1] < d[0];  // `if right_distance < left_distance` (bloom_tree.rs:201): ties go left
+                cur = went_right ? c.right : c.left;
+            } else if (c.is_leaf()) {
+                std::string name;
+                if (internal_name) name = internal_name;
+                else {
+                    do name = "Internal_Node_" + std::to_string(t.internal_counter++);
+                    while (std::find(t.filter_paths.begin(), t.filter_paths.end(), name + ".bf") != t.filter_paths.end());
+                }
+                HIP_TRY(t.d_build.ensure(8));
+                const uint32_t triple[3] = {int_row, c.filter, new_row};
+                HIP_TRY(hipMemcpy(t.d_build.p + 4, triple, 12, hipMemcpyHostToDevice));
+                pfq::launch_union(t.d_bits.p, t.n_words, t.d_build.p + 4, 1, nullptr);
+                HIP_TRY(hipGetLastError());
+                Node in;
+                in.has_tax = true;
+                in.tax_id = name;
+                in.bf_path = name + ".bf";
+                in.filter = int_row;
+                in.left = cur;   // the node already in the tree (bloom_tree.rs:241)
+                in.right = nv;   // the new leaf (:242)
+                t.filter_paths.push_back(in.bf_path);
+                const int32_t ni_h = (int32_t)t.nodes.size();
+                t.nodes.push_back(in);
+                if (parent < 0) t.root = ni_h;
+                else (went_right ? t.nodes[parent].right : t.nodes[parent].left) = ni_h;
+                break;
+            } else {
+                return fail(PFQ_ERR_FORMAT, "Node with only one child encountered - should not happen. (bloom_tree.rs:209)");
+            }
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        return PFQ_OK;
+    }
     // BloomTree::insert (bloom_tree.rs:128-143): the first leaf is the root; every later one is placed by the greedy descent,
     // which ends in a new internal node (left = the leaf it reached, right = the new leaf, filter = their union)
     int32_t ni = -1;

@@ -2821,15 +2821,17 @@ __global__ void __launch_bounds__(1024) k_greedy_insert(uint64_t *bits, uint64_t
                     a += s_l[w];
                     b += s_r[w];
                 }
-                mine[2u * blockIdx.x] = a;
-                mine[2u * blockIdx.x + 1u] = b;
+                // (written and read with read-modify-writes, which are performed at the memory side: the XCDs' L2s are not
+                // coherent with each other, and a plain load after the barrier could still see the line of two levels ago)
+                atomicExch(&mine[2u * blockIdx.x], a);
+                atomicExch(&mine[2u * blockIdx.x + 1u], b);
             }
             if (!grid_barrier(&bar[0], &bar[1], my_gen, &state[1])) return;
             // every block adds up all partials: the same sums, the same turn, everywhere
             dl = dr = 0;
             for (uint32_t b = threadIdx.x; b < G; b += blockDim.x) {
-                dl += mine[2u * b];
-                dr += mine[2u * b + 1u];
+                dl += atomicAdd(&mine[2u * b], 0ull);
+                dr += atomicAdd(&mine[2u * b + 1u], 0ull);
             }
             for (int d = 32; d > 0; d >>= 1) {
                 dl += __shfl_down(dl, d);

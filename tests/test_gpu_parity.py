@@ -578,6 +578,25 @@ def _gpu_greedy(genomes, ids, k, fpr, largest, seeds=(5, 10)):
     return gt
 
 
+def test_greedy_host_walk_knob(gpu, tmp_path):
+    """PFQ_GREEDY_HOST=1: the descent level by level from the host (no kernel with a grid barrier) builds the same database
+    as the one-launch walk on the device, and both equal the oracle's greedy insertion."""
+    genomes = [rand_dna(int(RNG.integers(300, 900))) for _ in range(37)]
+    genomes[9] = genomes[4]
+    ids = [f"h{i}" for i in range(len(genomes))]
+    ot = orc.build_greedy_tree(genomes, ids, 21, 0.001, 2000, 5, 10)
+    os.environ["PFQ_GREEDY_HOST"] = "1"
+    try:
+        gh = _gpu_greedy(genomes, ids, 21, 0.001, 2000)
+    finally:
+        del os.environ["PFQ_GREEDY_HOST"]
+    gd = _gpu_greedy(genomes, ids, 21, 0.001, 2000)
+    _assert_same_database(gh, ot, tmp_path, "host")
+    _assert_same_database(gd, ot, tmp_path, "device")
+    gh.close()
+    gd.close()
+
+
 def _assert_same_database(gt, ot, tmp_path, name):
     """Saved database == oracle tree: topology, names, leaf order and every node's filter."""
     from oracle import pfq_format as fmt
