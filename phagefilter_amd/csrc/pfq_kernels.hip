@@ -608,6 +608,30 @@ __device__ __forceinline__ bool has_batched_tail(uint64_t n, uint32_t tail_max) 
     return n > WIN_KMERS && n < (1ull << 32) && tl != 0 && tl <= tail_max;
 }
 
+// Reads of >= 256 k-mers are queued for the launch with wider counters.  The irregular reads of a dense group that belong
+// there are queued together — ONE atomic on the queue's cursor per group instead of one per read (a single address sustains
+// ~88 atomics/us: a block of 1000 bp reads spent 12 of its 30 ms there).  lane_len: the read's length on the first lane of
+// its lanes (0 elsewhere), rid_lo its index there; returns `irregular` without the queued reads.
+__device__ __forceinline__ uint32_t queue_long_reads(const QueryArgs &a, uint32_t irregular, uint64_t lane_len, uint32_t rid_lo, uint32_t lanes_log2) {
+    const uint32_t lane = lane_id(), jj = lane >> lanes_log2;
+    const bool first = (lane & ((1u << lanes_log2) - 1u)) == 0u;
+    const uint64_t n = lane_len >= a.hp.k ? lane_len - a.hp.k + 1 : 0, need = need_kmers(a.threshold, n);
+    const bool is_long = first && ((irregular >> jj) & 1u) && n >= SHORT_KMERS && need != 0 && need <= n;
+    const uint64_t m = ballot64(is_long);
+    if (!m) return irregular;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.n_long, (unsigned int)__popcll(m));
+    base = bcast_u32(base, 0);
+    if (is_long) a.long_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = rid_lo;
+    uint64_t mm = m;
+    while (mm) {
+        const uint32_t l = (uint32_t)__ffsll((unsigned long long)mm) - 1u;
+        mm &= mm - 1ull;
+        irregular &= ~(1u << (l >> lanes_log2));
+    }
+    return irregular;
+}
+
 // ---- the classification kernel ---------------------------------------------------------------------------------------
 // LPR_LOG2 (thresholds < 1): log2 of the lanes per read of the dense counting screen, rw = 4 << LPR_LOG2 (16, 32 or 64 row
 // words: a build per row width keeps the screen free of run-time shapes); 0: rows narrower than 16 words, per-read screen.
@@ -819,6 +843,7 @@ __global__ void __launch_bounds__(256, (COUNTS && !LONG && LPR_LOG2 != 0 && LPR_
                 process_read(LIST ? (uint64_t)bcast_u32(rid_lo, (int)(jj << lpr_log2)) : r0 + jj, dlds.live[wave] + jj * rw,
                              DEFER ? bcast_u32(n_rec, (int)(jj << lpr_log2)) : 0u);
             }
+            if (irregular) irregular = queue_long_reads(a, irregular, lane_len, rid_lo, lpr_log2);
             while (irregular) {
                 const uint32_t jj = (uint32_t)__ffs((int)irregular) - 1u;
                 irregular &= irregular - 1u;
@@ -1044,7 +1069,9 @@ __global__ void __launch_bounds__(256, 2) k_coarse(QueryArgs a, CoarseArgs ca) {
             __builtin_amdgcn_wave_barrier();
         }
     };
-    auto finish_group = [&](uint32_t survive, uint32_t irregular, uint32_t rid_lo, uint32_t lanes_log2) {
+    auto finish_group = [&](uint32_t survive, uint32_t irregular, uint32_t rid_lo, uint32_t lanes_log2, uint64_t lane_len) {
+        // (reads of >= 256 k-mers: queued for the second launch together; their bytes were counted with everybody's)
+        if (COUNTS && !LONG && irregular) irregular = queue_long_reads(a, irregular, lane_len, rid_lo, lanes_log2);
         if (!COUNTS) {
             if (survive) emit_batch(survive, rid_lo, lanes_log2);
             survive = 0;
@@ -1071,7 +1098,7 @@ __global__ void __launch_bounds__(256, 2) k_coarse(QueryArgs a, CoarseArgs ca) {
             const uint32_t survive = dense_screen<true>(dlds.mini[wave][0], dlds.mini[wave][1], s_comp, dlds.live[wave], a, nullptr, r0, cnt,
                                                         colmask, ca.n_probes, irregular, lane_len, rid);
             dense_bytes += lane_len;
-            finish_group(survive, irregular, rid, 2u);
+            finish_group(survive, irregular, rid, 2u, lane_len);
         }
     } else {
         constexpr uint32_t lpr_log2 = LPR_LOG2, rpw = 64u >> lpr_log2;
@@ -1086,7 +1113,7 @@ __global__ void __launch_bounds__(256, 2) k_coarse(QueryArgs a, CoarseArgs ca) {
                                                             LONG ? a.long_list : nullptr, r0, cnt, survive, irregular, lane_len, rid,
                                                             n_rec, ca.n_probes, ca.scr_extra);
             if (!LONG) dense_bytes += lane_len;  // (the first launch saw every read)
-            finish_group(survive, irregular, (uint32_t)rid, lpr_log2);
+            finish_group(survive, irregular, (uint32_t)rid, lpr_log2, lane_len);
         }
     }
     // unused slots of the last reservations
