@@ -176,7 +176,6 @@ __device__ __forceinline__ void kmer_hashes(const BlockLds &lds, uint32_t wave, 
 
 // ---- dense pre-screen staging: the first DENSE_KMERS k-mers of DENSE_READS reads per wave ------------------------------
 constexpr uint32_t DENSE_READS = 16, DENSE_KMERS = 4;               // 16 x 4 = 64 lanes
-constexpr uint32_t TAIL_KMERS = 16;                                  // a last window of <= 16 k-mers is batched, 4 reads per pass
 constexpr uint32_t MINI_BYTES = 84;                                  // >= WIN_PAD + (KMAX + DENSE_KMERS - 1) + WIN_PAD, dword multiple
 template <bool ENABLED>
 struct DenseLds {

@@ -177,6 +177,12 @@ def test_two_level_with_colliding_internal_names(gpu, tmp_path):
         for path in (0, 1):
             st = check_query(gt, ot, reads, thr, path=path)
             assert st.coarse_cols > 0 and st.path == path
+    # block mode behind the leaf groups of a tree with guard columns (the guards of the candidates that stand are certified
+    # against the sliced matrix, whose groups are 1024 columns wide here)
+    gt.set_option("PFQ_BLOCK", "1")
+    for thr in (1.0, 0.5):
+        st = check_query(gt, ot, reads, thr, path=1)
+        assert st.coarse_cols > 0 and st.tile_mode == 2
     gt.close()
 
 
