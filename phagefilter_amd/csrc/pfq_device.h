@@ -178,7 +178,7 @@ __device__ __forceinline__ void kmer_hashes(const BlockLds &lds, uint32_t wave, 
 constexpr uint32_t DENSE_READS = 16, DENSE_KMERS = 4;               // 16 x 4 = 64 lanes
 constexpr uint32_t MINI_BYTES = 84;                                  // >= WIN_PAD + (KMAX + DENSE_KMERS - 1) + WIN_PAD, dword multiple
 template <bool ENABLED>
-struct DenseLds {
+struct alignas(16) DenseLds {
     uint32_t mini[WAVES_PER_BLOCK][2][DENSE_READS * MINI_BYTES / 4];
     uint32_t live[WAVES_PER_BLOCK][DENSE_READS * 64];  // frontier words of the reads of a group, [read][row word]
 };

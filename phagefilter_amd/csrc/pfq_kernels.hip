@@ -280,6 +280,59 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
     const uint64_t present_b = ballot64(present && t == 0);
     uint32_t survive = 0;
     irregular = 0;
+    if constexpr (MULTI) {
+        // The coarse level's rows (4 k-mers x n_probes per read) are ANDed in REGISTERS: the row indices go through LDS (the
+        // staging buffers are free now; forward and reverse buffer are adjacent), rw / 4 lanes per read own 16 bytes of every
+        // row of their read, 64 / (rw / 4) reads per sub-pass, eight 16-byte gathers in flight per lane.  (Lanes as (row, part)
+        // with the indices picked by ds_bpermute and the AND finished by shuffles cost ~490 LDS-pipe instructions per pass of
+        // 16 reads against ~20 here: k_coarse at theta = 1 was bound by them.)
+        const uint32_t lpr_log2 = a.rw_log2 - 2u, lpr = 1u << lpr_log2, part = lane & (lpr - 1u), rows = DENSE_KMERS * ppk;
+        uint32_t cm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t w = part * 4u + u;
+            cm[u] = (w * 32u < a.n_leaves) ? ((a.n_leaves - w * 32u >= 32u) ? ~0u : ((1u << (a.n_leaves - w * 32u)) - 1u)) : 0u;
+        }
+        uint32_t *idx = fw;  // [read][k-mer][probe]: 64 x n_probes <= 384 of the 672 dwords
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t p = 0; p < COARSE_MAX_PROBES; ++p)
+            if (p < ppk) idx[lane * ppk + p] = valid ? ixs[p] : a.ones_row;  // (k-mers that do not exist: the all-ones row)
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t irr_b = ballot64(present && t == 0 && nk == 0);  // (no screening possible: the per-read path)
+        const uint32_t rps = 64u >> lpr_log2;  // reads per sub-pass
+        for (uint32_t j0 = 0; j0 < DENSE_READS; j0 += rps) {
+            const uint32_t jj = j0 + (lane >> lpr_log2);
+            const bool rd = jj < DENSE_READS && ((present_b >> (jj * 4u)) & 1ull) && !((irr_b >> (jj * 4u)) & 1ull);
+            const uint32_t *my = idx + (rd ? jj : 0u) * rows;
+            uint4 acc = make_uint4(~0u, ~0u, ~0u, ~0u);
+            for (uint32_t b = 0; b < rows; b += 8u) {
+                const uint4 xa = *reinterpret_cast<const uint4 *>(my + b);
+                const uint4 xb = *reinterpret_cast<const uint4 *>(my + (b + 4u < rows ? b + 4u : b));
+                const uint32_t xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                uint4 m[8];
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) {
+                    const uint32_t x = (rd && b + u < rows) ? xs[u] : a.ones_row;
+                    m[u] = *reinterpret_cast<const uint4 *>(a.S + (uint64_t)x * rw + part * 4u);
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) {
+                    acc.x &= m[u].x; acc.y &= m[u].y; acc.z &= m[u].z; acc.w &= m[u].w;
+                }
+            }
+            acc.x &= cm[0]; acc.y &= cm[1]; acc.z &= cm[2]; acc.w &= cm[3];
+            const uint64_t bal = ballot64(rd && (acc.x | acc.y | acc.z | acc.w) != 0u);
+            const uint64_t mine_b = (bal >> ((lane >> lpr_log2) << lpr_log2)) & (lpr >= 64u ? ~0ull : ((1ull << lpr) - 1ull));
+            if (rd && mine_b) *reinterpret_cast<uint4 *>(live_out + jj * rw + part * 4u) = acc;
+            for (uint32_t r = 0; r < rps && j0 + r < DENSE_READS; ++r)
+                if ((bal >> (r << lpr_log2)) & (lpr >= 64u ? ~0ull : ((1ull << lpr) - 1ull))) survive |= 1u << (j0 + r);
+        }
+        for (uint32_t jj = 0; jj < DENSE_READS; ++jj)
+            if ((irr_b >> (jj * 4u)) & 1ull) irregular |= 1u << jj;
+        __builtin_amdgcn_wave_barrier();
+        return survive;
+    }
     // Row gathers, 16 bytes per lane: a read's 2*nk rows of rw dwords are covered by lanes (row = lane / (rw/4),
     // part = lane % (rw/4)); with rw = 32 one load instruction fetches all 8 rows of a read.  The loads of
     // DENSE_BATCH reads are issued before any is consumed.  (rw >= 4 here; smaller trees skip the pre-screen.)
