@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpfq.so")
+# (PFQ_LIBPFQ: another build of the library, for A/B measurements of two builds on one box)
+LIB_PATH = os.environ.get("PFQ_LIBPFQ") or os.path.join(_HERE, "libpfq.so")
 
 # every symbol include/pfq.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

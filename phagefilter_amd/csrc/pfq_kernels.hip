@@ -280,8 +280,12 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
     const uint64_t present_b = ballot64(present && t == 0);
     uint32_t survive = 0;
     irregular = 0;
+#ifdef PFQ_DENSE_V1
     if constexpr (MULTI) {
-        // The coarse level's rows (4 k-mers x n_probes per read) are ANDed in REGISTERS: the row indices go through LDS (the
+#else
+    {
+#endif
+        // The screening rows (4 k-mers x 2 probes per read; n_probes at the coarse level) are ANDed in REGISTERS: the row indices go through LDS (the
         // staging buffers are free now; forward and reverse buffer are adjacent), rw / 4 lanes per read own 16 bytes of every
         // row of their read, 64 / (rw / 4) reads per sub-pass, eight 16-byte gathers in flight per lane.  (Lanes as (row, part)
         // with the indices picked by ds_bpermute and the AND finished by shuffles cost ~490 LDS-pipe instructions per pass of
@@ -295,9 +299,14 @@ __device__ __forceinline__ uint32_t dense_screen(uint32_t *fw, uint32_t *rw_, co
         }
         uint32_t *idx = fw;  // [read][k-mer][probe]: 64 x n_probes <= 384 of the 672 dwords
         __builtin_amdgcn_wave_barrier();
+        if constexpr (MULTI) {
 #pragma unroll
-        for (uint32_t p = 0; p < COARSE_MAX_PROBES; ++p)
-            if (p < ppk) idx[lane * ppk + p] = valid ? ixs[p] : a.ones_row;  // (k-mers that do not exist: the all-ones row)
+            for (uint32_t p = 0; p < COARSE_MAX_PROBES; ++p)
+                if (p < ppk) idx[lane * ppk + p] = valid ? ixs[p] : a.ones_row;  // (k-mers that do not exist: the all-ones row)
+        } else {
+            idx[lane * 2u] = valid ? i0v : a.ones_row;
+            idx[lane * 2u + 1u] = (valid && two) ? i1v : a.ones_row;
+        }
         __builtin_amdgcn_wave_barrier();
         const uint64_t irr_b = ballot64(present && t == 0 && nk == 0);  // (no screening possible: the per-read path)
         const uint32_t rps = 64u >> lpr_log2;  // reads per sub-pass
