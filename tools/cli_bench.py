@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--leaves", type=int, default=64)
     ap.add_argument("--threshold", default="1.0", help="-f of every query run")
     ap.add_argument("--block", default="100000", help="-b of every query run")
+    ap.add_argument("--only", default="", help="'posneg': only the run with both outputs (environment variables reach the CLI)")
     ap.add_argument("--devices", default="", help="comma-separated device lists to run as well, ';'-separated (e.g. '0,0' = two replicas on GPU 0)")
     a = ap.parse_args()
     import torch
@@ -107,9 +108,14 @@ def main():
                           "whole_process_reads_per_s": round(n_reads / wall), "query_loop": loop[0] if loop else None,
                           "ingest": ingest[0] if ingest else None, "output": outl[0] if outl else None, "cpu": cpul[0] if cpul else None, "classified": sum(int(l.split(",")[1]) for l in csv)}), flush=True)
 
+    tmax = max(int(x) for x in a.threads.split(","))
+    if a.only == "posneg":
+        for rep in range(2):
+            run("fastq pos+neg output", fq, a.reads, tmax, ("--pos-filter", "--neg-filter"))
+        shutil.rmtree(a.workdir, ignore_errors=True)
+        return
     for t in [int(x) for x in a.threads.split(",")]:
         run("fastq counts-only", fq, a.reads, t)
-    tmax = max(int(x) for x in a.threads.split(","))
     run("fastq pos+neg output", fq, a.reads, tmax, ("--pos-filter", "--neg-filter"))
     for devs in [d for d in a.devices.split(";") if d]:
         run(f"fastq counts-only --devices {devs}", fq, a.reads, tmax, ("--devices", devs))
