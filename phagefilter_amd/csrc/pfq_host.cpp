@@ -1046,7 +1046,10 @@ struct QueryRun {
             t.last_coarse_cols = t.coarse_cols;
             t.last_coarse_probes = np;
             HIP_TRY(hipMemsetAsync(t.d_gcur.p, 0, 2 * pfq::MAX_LEAF_GROUPS * sizeof(unsigned int), st));  // lists' cursors, long reads' cursors
-            pfq::launch_coarse(ac, ca, counts_mode, blocks, st);
+            // (1024 blocks: every wave of the coarse launch may leave a reservation of 32 slots partly used in every group's list —
+            // with 4096 blocks and ten groups the lists were half unused slots, and the leaf groups' dense screens half idle)
+            int coarse_blocks = std::min(blocks, 1024);
+            pfq::launch_coarse(ac, ca, counts_mode, coarse_blocks, st);
         }
         if (two_level) {
             // ONE launch for all leaf groups (blockIdx.y = the group: its matrix, columns and list follow from it); the
