@@ -19,6 +19,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/pfq.h"
@@ -144,6 +145,7 @@ struct pfq_tree {
     uint64_t kmer_size = 0, nbits = 0, seed1 = 0, seed2 = 0, n_words = 0;
     uint32_t num_hashes = 0;
     std::vector<std::string> filter_paths;
+    std::unordered_set<std::string> path_set;  // filter_paths as a set, kept by pfq_tree_insert (a name's .bf must be new: a scan per insertion was 40 us at 2000 nodes)
     std::vector<uint8_t> edge_ok;  // per node: parent(v) ⊇ v verified
     bool superset_all = true;
     uint64_t shard_first_leaf = 0, tree_leaves = 0;  // subtree shards (pfq_tree_open_subtree)
@@ -161,17 +163,21 @@ struct pfq_tree {
     uint64_t internal_counter = 0;     // names of internal nodes created by pfq_tree_insert
     size_t n_rows = 0, row_capacity = 0;  // filter rows in use / allocated in d_bits
     DevBuf<uint32_t> d_build;          // insert scratch: leaf row, union triple
-    DevBuf<unsigned long long> d_dist; // insert scratch: per-block partial Hamming distances (left, right) of two levels
+    DevBuf<unsigned long long> d_dist; // insert scratch: the device walk's barrier lines (GREEDY_SYNC_*); the host walk's per-block partials
     // pfq_tree_insert walks the tree on the device (k_greedy_insert): its shape is mirrored there and the host's left / right /
     // root are brought up to date when they are next needed (finish_topology)
     DevBuf<pfq::TopoNode> d_topo;
-    DevBuf<int> d_walk;                // [0] root, [1] error word, [2..3] the grid barrier's arrival count and generation
+    DevBuf<int> d_walk;                // [0] root (for the host), [1] error word, [2..3] the root as the walk's launches hand it on
     bool topo_on_device = false;       // d_topo / d_walk mirror the host's nodes
     bool topo_pending = false;         // insertions ran since the host last read the shape back
     DevBuf<uint8_t> d_gseq[4];         // genomes of the insertions in flight (ring)
     hipEvent_t gseq_free[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t gseq_copied[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint8_t *h_gseq[4] = {nullptr, nullptr, nullptr, nullptr};  // page-locked staging of the same ring (the caller's buffer is free when pfq_tree_insert returns)
+    size_t h_gseq_n[4] = {0, 0, 0, 0};
     uint32_t gseq_next = 0;
     int greedy_blocks = 0;
+    uint32_t walk_seq = 0;             // launches of the device walk since d_walk was written (parity: where the root is read / left)
 
     pfq::HashParams hp{};
     // ---- device: node-major filters
@@ -1992,7 +1998,11 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
     // One .bf per node here.  (The reference keys filters by file name: a second node called <tax_id> gets a fresh empty
     // filter under the first one's key, bloom_tree.rs:294 / cache.rs:83-87, and the two then share one file on disk —
     // SURVEY H4.  Such databases can be OPENED; building one is refused.)
-    auto path_taken = [&](const std::string &pth) { return std::find(t.filter_paths.begin(), t.filter_paths.end(), pth) != t.filter_paths.end(); };
+    if (t.path_set.size() != t.filter_paths.size()) {
+        t.path_set.clear();
+        t.path_set.insert(t.filter_paths.begin(), t.filter_paths.end());
+    }
+    auto path_taken = [&](const std::string &pth) { return t.path_set.count(pth) != 0; };
     if (path_taken(std::string(tax_id) + ".bf"))
         return fail(PFQ_ERR_ARG, std::string("a node named ") + tax_id + " exists already: two nodes would share " + tax_id + ".bf");
     if (internal_name && (path_taken(std::string(internal_name) + ".bf") || !strcmp(internal_name, tax_id)))
@@ -2003,8 +2013,8 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
     if (!t.greedy_blocks) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, t.device));
-        // every block must be resident (one per CU at most); blocks of 1024 threads, half as many as CUs: enough to stream the
-        // filters, few enough pollers at the barrier
+        // every block must be resident (one per CU at most); blocks of 1024 threads, half as many as CUs: they stream the filters
+        // as fast as all would (measured: 128 blocks 5300, 192 5270, 256 4790 genomes/s)
         int want = prop.multiProcessorCount / 2;
         if (const char *e = getenv("PFQ_GREEDY_BLOCKS")) want = atoi(e);
         t.greedy_blocks = std::max(1, std::min(std::min(pfq::GREEDY_MAX_BLOCKS, prop.multiProcessorCount), want));
@@ -2018,11 +2028,14 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
         const size_t cap = std::max<size_t>(n_after, 2 * t.d_topo.n + 1024);
         HIP_TRY(t.d_topo.ensure(cap));
         HIP_TRY(t.d_walk.ensure(4));
-        HIP_TRY(t.d_dist.ensure(std::max<size_t>(4 * (size_t)pfq::GREEDY_MAX_BLOCKS, 2 * (size_t)pfq::INSERT_STEP_BLOCKS)));
+        const size_t sync_words = (size_t)pfq::GREEDY_SYNC_LINES * pfq::GREEDY_SYNC_STRIDE / 8;
+        HIP_TRY(t.d_dist.ensure(std::max<size_t>(sync_words, 2 * (size_t)pfq::INSERT_STEP_BLOCKS)));
+        HIP_TRY(hipMemset(t.d_dist.p, 0, sync_words * 8));  // the walk's counters, generation words and accumulators start clear
         std::vector<pfq::TopoNode> h(t.nodes.size());
         for (size_t v = 0; v < h.size(); ++v) h[v] = pfq::TopoNode{t.nodes[v].left, t.nodes[v].right, t.nodes[v].filter, 0u};
         if (!h.empty()) HIP_TRY(hipMemcpy(t.d_topo.p, h.data(), h.size() * sizeof(pfq::TopoNode), hipMemcpyHostToDevice));
-        const int st[4] = {t.root, 0, 0, 0};
+        const int st[4] = {t.root, 0, t.root, t.root};
+        t.walk_seq = 0;
         HIP_TRY(hipMemcpy(t.d_walk.p, st, sizeof st, hipMemcpyHostToDevice));
         t.topo_on_device = true;
     }
@@ -2034,13 +2047,29 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
         HIP_TRY(hipStreamCreateWithFlags(&t.copy_stream, hipStreamNonBlocking));
         for (auto &e : t.in_free) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    if (!t.gseq_free[slot]) HIP_TRY(hipEventCreateWithFlags(&t.gseq_free[slot], hipEventDisableTiming));
-    else HIP_TRY(hipEventSynchronize(t.gseq_free[slot]));   // the insertion that used this buffer four calls ago has read it
+    if (!t.gseq_free[slot]) {
+        HIP_TRY(hipEventCreateWithFlags(&t.gseq_free[slot], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&t.gseq_copied[slot], hipEventDisableTiming));
+    } else HIP_TRY(hipEventSynchronize(t.gseq_free[slot]));   // the insertion that used these buffers four calls ago has read them
     if (t.d_gseq[slot].n < len + 16) {
         HIP_TRY(t.d_gseq[slot].ensure(std::max<size_t>(len + 16, 2 * t.d_gseq[slot].n)));
     }
-    if (len) HIP_TRY(hipMemcpyAsync(t.d_gseq[slot].p, seq, len, hipMemcpyHostToDevice, t.copy_stream));
-    HIP_TRY(hipStreamSynchronize(t.copy_stream));  // (its own stream: does not wait for the kernels of the insertions before)
+    if (t.h_gseq_n[slot] < len + 16) {
+        if (t.h_gseq[slot]) HIP_TRY(hipHostFree(t.h_gseq[slot]));
+        t.h_gseq[slot] = nullptr;
+        t.h_gseq_n[slot] = 0;
+        const size_t want = std::max<size_t>(len + 16, 2 * t.h_gseq_n[slot]);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&t.h_gseq[slot]), want, hipHostMallocDefault));
+        t.h_gseq_n[slot] = want;
+    }
+    // (through page-locked staging on a stream of its own: the copy neither waits for the kernels of the insertions before
+    // nor holds the caller — the kernels wait for it by event)
+    if (len) {
+        memcpy(t.h_gseq[slot], seq, len);
+        HIP_TRY(hipMemcpyAsync(t.d_gseq[slot].p, t.h_gseq[slot], len, hipMemcpyHostToDevice, t.copy_stream));
+    }
+    HIP_TRY(hipEventRecord(t.gseq_copied[slot], t.copy_stream));
+    HIP_TRY(hipStreamWaitEvent(nullptr, t.gseq_copied[slot], 0));
     HIP_TRY(hipMemsetAsync(t.d_bits.p + (uint64_t)new_row * t.n_words, 0, t.n_words * 8, nullptr));
     pfq::launch_insert_one(t.hp, t.d_gseq[slot].p, len, new_row, t.d_bits.p, t.n_words, nullptr);
     HIP_TRY(hipEventRecord(t.gseq_free[slot], nullptr));
@@ -2050,6 +2079,7 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
     leaf.bf_path = std::string(tax_id) + ".bf";
     leaf.filter = new_row;
     t.filter_paths.push_back(leaf.bf_path);
+    t.path_set.insert(leaf.bf_path);
     const int32_t nv = (int32_t)t.nodes.size();
     t.nodes.push_back(leaf);
     t.topology_dirty = true;
@@ -2086,7 +2116,7 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
                 if (internal_name) name = internal_name;
                 else {
                     do name = "Internal_Node_" + std::to_string(t.internal_counter++);
-                    while (std::find(t.filter_paths.begin(), t.filter_paths.end(), name + ".bf") != t.filter_paths.end());
+                    while (path_taken(name + ".bf"));
                 }
                 HIP_TRY(t.d_build.ensure(8));
                 const uint32_t triple[3] = {int_row, c.filter, new_row};
@@ -2101,6 +2131,7 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
                 in.left = cur;   // the node already in the tree (bloom_tree.rs:241)
                 in.right = nv;   // the new leaf (:242)
                 t.filter_paths.push_back(in.bf_path);
+                t.path_set.insert(in.bf_path);
                 const int32_t ni_h = (int32_t)t.nodes.size();
                 t.nodes.push_back(in);
                 if (parent < 0) t.root = ni_h;
@@ -2121,7 +2152,7 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
         if (internal_name) name = internal_name;
         else {
             do name = "Internal_Node_" + std::to_string(t.internal_counter++);
-            while (std::find(t.filter_paths.begin(), t.filter_paths.end(), name + ".bf") != t.filter_paths.end());
+            while (path_taken(name + ".bf"));
         }
         Node in;
         in.has_tax = true;
@@ -2130,14 +2161,14 @@ int pfq_tree_insert(pfq_tree *tree, const uint8_t *seq, uint64_t len, const char
         in.filter = int_row;
         in.right = nv;   // the new leaf (:242); `left` = the leaf the walk reaches, known on the device (sync_topology)
         t.filter_paths.push_back(in.bf_path);
+        t.path_set.insert(in.bf_path);
         ni = (int32_t)t.nodes.size();
         t.nodes.push_back(in);
     } else {
         --t.n_rows;  // (no internal node: its row is not used)
     }
     if (ni < 0) t.root = nv;  // (the host's root is only a hint while insertions are pending; empty vs. not is what counts)
-    pfq::launch_greedy_insert(t.d_bits.p, t.n_words, t.d_topo.p, t.d_walk.p, reinterpret_cast<unsigned int *>(t.d_walk.p + 2), t.d_dist.p, nv,
-                              ni < 0 ? nv : ni, new_row, int_row, t.greedy_blocks, nullptr);
+    pfq::launch_greedy_insert(t.d_bits.p, t.n_words, t.d_topo.p, t.d_walk.p, t.d_dist.p, nv, ni < 0 ? nv : ni, new_row, int_row, t.walk_seq++, t.greedy_blocks, nullptr);
     HIP_TRY(hipGetLastError());
     t.topo_pending = true;
     return PFQ_OK;
@@ -2293,6 +2324,10 @@ void pfq_tree_close(pfq_tree *tree) {
     }
     for (auto e : tree->gseq_free)
         if (e) (void)hipEventDestroy(e);
+    for (auto e : tree->gseq_copied)
+        if (e) (void)hipEventDestroy(e);
+    for (auto h : tree->h_gseq)
+        if (h) (void)hipHostFree(h);
     if (tree->h_hit_off) (void)hipHostFree(tree->h_hit_off);
     if (tree->h_hit_leaves) (void)hipHostFree(tree->h_hit_leaves);
 

@@ -304,17 +304,20 @@ void launch_insert(const HashParams &hp, const uint8_t *d_genomes, const uint64_
 // one genome (device memory, len bytes) into filter row `row`
 void launch_insert_one(const HashParams &hp, const uint8_t *d_genome, uint64_t len, uint32_t row, uint64_t *bits, uint64_t n_words, hipStream_t st);
 // The greedy placement of one new leaf (BloomTree::insert, bloom_tree.rs:187-245) walked on the device in one launch; the tree's
-// shape is mirrored in device memory: a TopoNode per node, state[0] = the root's index (-1: empty), state[1] = error word
-// (1: a node with one child was met; 2: the grid's barrier timed out), bar = {arrival count, generation} of the grid barrier,
-// partials = 2 x 2 x blocks u64.  `blocks` must not exceed the number of CUs (every block has to be resident).
+// shape is mirrored in device memory: a TopoNode per node, state[0] = the root's index (-1: empty; state[2 + (seq & 1)] is
+// where launch number seq reads it, state[2 + (~seq & 1)] where it leaves it), state[1] = error word
+// (1: a node with one child was met; 2: the grid's barrier timed out), sync = GREEDY_SYNC_LINES lines of GREEDY_SYNC_STRIDE
+// bytes, zeroed once (the barrier's counters, generation words and distance accumulators, a line each: see grid_turn).
+// `blocks` must not exceed the number of CUs (every block has to be resident).
 struct TopoNode {
     int32_t left, right;   // node indices, -1: none
     uint32_t row;          // filter row
     uint32_t pad_;
 };
-constexpr int GREEDY_MAX_BLOCKS = 256;  // (sizes the partial sums; the launch uses fewer: see pfq_tree_insert)
-void launch_greedy_insert(uint64_t *bits, uint64_t n_words, TopoNode *topo, int *state, unsigned int *bar, unsigned long long *partials,
-                          int leaf_node, int internal_node, uint32_t new_row, uint32_t int_row, int blocks, hipStream_t st);
+constexpr int GREEDY_MAX_BLOCKS = 256;
+constexpr uint32_t GREEDY_SYNC_STRIDE = 4096, GREEDY_SYNC_LINES = 49;
+void launch_greedy_insert(uint64_t *bits, uint64_t n_words, TopoNode *topo, int *state, unsigned long long *sync, int leaf_node, int internal_node,
+                          uint32_t new_row, uint32_t int_row, uint32_t seq, int blocks, hipStream_t st);
 // dst[i] = a[i] | b[i] over rows given as triples (dst,a,b); b == 0xffffffff: copy a.
 void launch_union(uint64_t *bits, uint64_t n_words, const uint32_t *d_triples, uint32_t n_triples, hipStream_t st);
 // bits[cur] |= bits[new]; per-block partial Hamming distances: sum_b d_out[2b] = hamming(bits[left], bits[new]),

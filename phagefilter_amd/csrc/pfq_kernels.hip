@@ -2823,7 +2823,10 @@ void launch_insert(const HashParams &hp, const uint8_t *d_genomes, const uint64_
     hipLaunchKernelGGL(k_insert, dim3(64, n_genomes), dim3(256), 0, st, hp, d_genomes, d_goff, d_leaf_row, bits, n_words, 0ull, 0u);
 }
 void launch_insert_one(const HashParams &hp, const uint8_t *d_genome, uint64_t len, uint32_t row, uint64_t *bits, uint64_t n_words, hipStream_t st) {
-    hipLaunchKernelGGL(k_insert, dim3(64, 1), dim3(256), 0, st, hp, d_genome, (const uint64_t *)nullptr, (const uint32_t *)nullptr, bits, n_words, len, row);
+    // (a window of 64 k-mers per wave where the genome is short enough: the atomics of a window wait for nothing but each other)
+    const uint64_t windows = (len + WIN_KMERS - 1) / WIN_KMERS;
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, (windows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+    hipLaunchKernelGGL(k_insert, dim3(blocks, 1), dim3(256), 0, st, hp, d_genome, (const uint64_t *)nullptr, (const uint32_t *)nullptr, bits, n_words, len, row);
 }
 
 // ---- BloomTree::insert's greedy descent (add_to_tree, bloom_tree.rs:187-245) in ONE launch -------------------------------
@@ -2833,65 +2836,138 @@ void launch_insert_one(const HashParams &hp, const uint8_t *d_genome, uint64_t l
 // topology lives in device memory (TopoNode per node, the root's index), so consecutive insertions need no host round trip:
 // the host only learns the shape when it next needs it.  The blocks of the grid meet at a barrier once per level (all of them
 // are resident: one per CU); every block then adds up the per-block partial distances itself, so all take the same turn.
-// A barrier that is not passed within a bounded number of polls sets the error word and every block leaves: the grid drains.
-__device__ __forceinline__ bool grid_barrier(unsigned int *count, unsigned int *gen, unsigned int &my_gen, int *err) {
-    __shared__ int s_ok;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned int prev = atomicAdd(count, 1u);
-        if (prev == gridDim.x - 1u) {
-            atomicExch(count, 0u);
-            __threadfence();
-            atomicAdd(gen, 1u);
-        } else {
-            // (polled with a read-modify-write, which is performed at the memory side: a device-scope LOAD was seen to stay on a
-            // stale line of the poller's own XCD L2 — barriers timed out.  Few blocks, so that the pollers do not queue up.)
+// A barrier that is not passed within a bounded number of polls sets the error word and the block leaves; the others then
+// time out as well: the grid drains.
+//
+// The barrier carries the level's decision.  Everything the blocks exchange goes through read-modify-writes, which are
+// performed at the memory side (the XCDs' L2s are not coherent with each other: a load was seen to stay on a stale line), and
+// a line takes only ~90 of them per microsecond — so the words are spread over lines of their own, GREEDY_SYNC_STRIDE apart:
+//   group g = block & 15: an arrival counter, a pair of distance accumulators (left, right) and a copy of the generation word;
+//   one top counter for the groups.
+// A block adds its distances to its group's accumulators and arrives at its group's counter; the last of a group arrives at
+// the top counter; the last of all collects (and clears) the 16 pairs of accumulators with one exchange per lane, takes the
+// turn and publishes [generation:31][turn:1] in the 16 generation words, where each group polls its own copy.  (Before:
+// one counter and one generation word for 128 pollers, the partial sums of every block read back by every block: ~20 us per
+// level, of which the filters' streaming is 9.)
+__device__ __forceinline__ uint32_t *sync_word(unsigned long long *sync, uint32_t line) {
+    return reinterpret_cast<uint32_t *>(sync + (uint64_t)line * (GREEDY_SYNC_STRIDE / 8u));
+}
+// Returns 0 / 1 = the turn (right iff strictly closer), -1 = timed out.  Called by every thread of the block; dl / dr are the
+// block's sums, valid in thread 0.
+__device__ __forceinline__ int grid_turn(unsigned long long *sync, unsigned int &my_gen, unsigned long long dl, unsigned long long dr, int *err) {
+    __shared__ int s_turn;
+    const uint32_t G = gridDim.x, g = blockIdx.x & 15u, n_groups = G < 16u ? G : 16u, in_group = (G - g + 15u) / 16u;
+    uint32_t *top = sync_word(sync, 0), *gcount = sync_word(sync, 1u + g), *gen = sync_word(sync, 17u + g);
+    __syncthreads();  // the block's stores of this level are issued
+    if (threadIdx.x < 64) {  // wave 0
+        const uint32_t lane = threadIdx.x;
+        int last = 0;
+        if (lane == 0) {
+            unsigned long long *acc = sync + (uint64_t)(33u + g) * (GREEDY_SYNC_STRIDE / 8u);
+            atomicAdd(&acc[0], dl);
+            atomicAdd(&acc[1], dr);
+            __threadfence();  // the block's node_union stores and its sums are performed before it arrives
+            if (atomicAdd(gcount, 1u) == in_group - 1u) {
+                // (the counter is clear BEFORE the group is reported: with small filters a block of the group is back here
+                // within a microsecond of the generation's change, and a clearing still on its way would wipe its arrival)
+                atomicExch(gcount, 0u);
+                __threadfence();
+                if (atomicAdd(top, 1u) == n_groups - 1u) {
+                    atomicExch(top, 0u);
+                    last = 1;
+                }
+            }
+        }
+        last = __builtin_amdgcn_readfirstlane(last);
+        int turn = -1;
+        if (last) {
+            // every block has arrived: lanes 0..31 fetch and clear one accumulator each (left of group lane/2 for even lanes)
+            unsigned long long v = 0;
+            if (lane < 2u * n_groups) v = atomicExch(sync + (uint64_t)(33u + (lane >> 1)) * (GREEDY_SYNC_STRIDE / 8u) + (lane & 1u), 0ull);
+            unsigned long long l = (lane & 1u) ? 0ull : v, r = (lane & 1u) ? v : 0ull;
+            for (int d = 16; d > 0; d >>= 1) {
+                l += __shfl_down(l, d);
+                r += __shfl_down(r, d);
+            }
+            l = bcast_u64(l, 0);
+            r = bcast_u64(r, 0);
+            turn = r < l ? 1 : 0;  // `if right_distance < left_distance` (bloom_tree.rs:201): ties go left
+            __threadfence();        // (the top counter's clearing, too, is performed before anybody can arrive again)
+            if (lane < n_groups) atomicExch(sync_word(sync, 17u + lane), (((my_gen + 1u) & 0x7fffffffu) << 1) | (uint32_t)turn);
+        } else if (lane == 0) {
             unsigned int polls = 0;
-            while (atomicAdd(gen, 0u) == my_gen) {
-                __builtin_amdgcn_s_sleep(2);
+            while (true) {
+                const uint32_t v = atomicAdd(gen, 0u);
+                if ((v >> 1) != my_gen) {
+                    turn = (int)(v & 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
                 if (++polls > (1u << 21)) {  // (seconds: some block of the grid never arrived)
                     atomicExch(err, 2);
                     break;
                 }
             }
+            __threadfence();
         }
-        __threadfence();
-        s_ok = atomicAdd(err, 0) == 0;
+        if (lane == 0) s_turn = turn;
     }
-    ++my_gen;
+    my_gen = (my_gen + 1u) & 0x7fffffffu;
     __syncthreads();
-    return s_ok != 0;
+    return s_turn;
 }
-__global__ void __launch_bounds__(1024) k_greedy_insert(uint64_t *bits, uint64_t n_words, TopoNode *topo, int *state /* root, err */,
-                                                        unsigned int *bar /* count, generation */, unsigned long long *partials,
-                                                        int leaf_node, int internal_node, uint32_t new_row, uint32_t int_row) {
+// The root is read from state[2 + (seq & 1)] and handed on in state[2 + (~seq & 1)], seq = the launch's number: a walk that ends
+// at the root itself passes no barrier, and block 0 would otherwise install the new root while blocks that start late still
+// read the old one (they would take the new internal node for the walk's first level and wait at a barrier nobody comes to).
+__global__ void __launch_bounds__(1024) k_greedy_insert(uint64_t *bits, uint64_t n_words, TopoNode *topo, int *state /* root, err, root in/out */,
+                                                        unsigned long long *sync, int leaf_node, int internal_node, uint32_t new_row, uint32_t int_row,
+                                                        uint32_t seq) {
     __shared__ unsigned long long s_l[16], s_r[16];
-    __shared__ unsigned long long s_dl, s_dr;
+    __shared__ unsigned int s_gen;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, G = gridDim.x;
-    unsigned int my_gen = 0;
-    if (threadIdx.x == 0) s_dl = atomicAdd(&bar[1], 0u);
+    // (the generation the block's copy holds when this launch starts; nobody changes it before all have read it: the first
+    //  change needs every block's arrival)
+    if (threadIdx.x == 0) s_gen = atomicAdd(sync_word(sync, 17u + (blockIdx.x & 15u)), 0u) >> 1;
     __syncthreads();
-    my_gen = (unsigned int)s_dl;   // (the generation the barrier word holds when this launch starts; nobody bumps it before all have read it:
-                                   //  the first bump needs every block's arrival)
+    unsigned int my_gen = s_gen;
     const uint64_t *nw = bits + (uint64_t)new_row * n_words;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)G * blockDim.x;
-    int cur = state[0], parent = -1, side = 0;
+    int *root_out = &state[2u + (~seq & 1u)];
+    int cur = state[2u + (seq & 1u)], parent = -1, side = 0;
     if (threadIdx.x == 0 && blockIdx.x == 0) topo[leaf_node] = TopoNode{-1, -1, new_row, 0u};
     if (cur < 0) {  // empty tree: the new leaf is the root
-        if (threadIdx.x == 0 && blockIdx.x == 0) state[0] = leaf_node;
+        if (threadIdx.x == 0 && blockIdx.x == 0) state[0] = *root_out = leaf_node;
         return;
     }
-    for (uint32_t level = 0;; ++level) {
+    const int root = cur;
+    while (true) {
         const TopoNode c = topo[cur];
         if (c.left >= 0 && c.right >= 0) {
             uint64_t *crow = bits + (uint64_t)c.row * n_words;
             const uint64_t *l = bits + (uint64_t)topo[c.left].row * n_words, *r = bits + (uint64_t)topo[c.right].row * n_words;
             unsigned long long dl = 0, dr = 0;
-            for (uint64_t i = tid; i < n_words; i += nthreads) {
+            uint64_t i = tid;
+            // (four words per thread and filter in flight: a thread sees ~9 of each filter's words)
+            for (; i + 3u * nthreads < n_words; i += 4u * nthreads) {
+                uint64_t v[4], cv[4], lv[4], rv[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    v[u] = nw[i + u * nthreads];
+                    cv[u] = crow[i + u * nthreads];
+                    lv[u] = l[i + u * nthreads];
+                    rv[u] = r[i + u * nthreads];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    crow[i + u * nthreads] = cv[u] | v[u];                       // node_union (bloom_tree.rs:194)
+                    dl += (unsigned long long)__popcll(lv[u] ^ v[u]);          // distance (bloom_filter.rs:142-149)
+                    dr += (unsigned long long)__popcll(rv[u] ^ v[u]);
+                }
+            }
+            for (; i < n_words; i += nthreads) {
                 const uint64_t v = nw[i];
-                crow[i] |= v;                                            // node_union (bloom_tree.rs:194)
-                dl += (unsigned long long)__popcll(l[i] ^ v);          // distance (bloom_filter.rs:142-149)
+                crow[i] |= v;
+                dl += (unsigned long long)__popcll(l[i] ^ v);
                 dr += (unsigned long long)__popcll(r[i] ^ v);
             }
             for (int d = 32; d > 0; d >>= 1) {
@@ -2903,48 +2979,17 @@ __global__ void __launch_bounds__(1024) k_greedy_insert(uint64_t *bits, uint64_t
                 s_r[wave] = dr;
             }
             __syncthreads();
-            unsigned long long *mine = partials + (uint64_t)(level & 1u) * 2u * G;
-            if (threadIdx.x == 0) {
-                unsigned long long a = 0, b = 0;
-                for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
-                    a += s_l[w];
-                    b += s_r[w];
-                }
-                // (written and read with read-modify-writes, which are performed at the memory side: the XCDs' L2s are not
-                // coherent with each other, and a plain load after the barrier could still see the line of two levels ago)
-                atomicExch(&mine[2u * blockIdx.x], a);
-                atomicExch(&mine[2u * blockIdx.x + 1u], b);
-            }
-            if (!grid_barrier(&bar[0], &bar[1], my_gen, &state[1])) return;
-            // every block adds up all partials: the same sums, the same turn, everywhere
             dl = dr = 0;
-            for (uint32_t b = threadIdx.x; b < G; b += blockDim.x) {
-                dl += atomicAdd(&mine[2u * b], 0ull);
-                dr += atomicAdd(&mine[2u * b + 1u], 0ull);
-            }
-            for (int d = 32; d > 0; d >>= 1) {
-                dl += __shfl_down(dl, d);
-                dr += __shfl_down(dr, d);
-            }
-            if (lane == 0) {
-                s_l[wave] = dl;
-                s_r[wave] = dr;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned long long a = 0, b = 0;
+            if (threadIdx.x == 0)
                 for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
-                    a += s_l[w];
-                    b += s_r[w];
+                    dl += s_l[w];
+                    dr += s_r[w];
                 }
-                s_dl = a;
-                s_dr = b;
-            }
-            __syncthreads();
+            const int turn = grid_turn(sync, my_gen, dl, dr, &state[1]);
+            if (turn < 0) return;
             parent = cur;
-            side = s_dr < s_dl ? 1 : 0;   // `if right_distance < left_distance` (bloom_tree.rs:201): ties go left
+            side = turn;
             cur = side ? c.right : c.left;
-            __syncthreads();              // (s_dl / s_dr are rewritten at the next level)
         } else if (c.left < 0 && c.right < 0) {
             // the leaf is replaced by a new internal node over it and the new leaf (bloom_tree.rs:226-245)
             uint64_t *irow = bits + (uint64_t)int_row * n_words;
@@ -2952,9 +2997,11 @@ __global__ void __launch_bounds__(1024) k_greedy_insert(uint64_t *bits, uint64_t
             for (uint64_t i = tid; i < n_words; i += nthreads) irow[i] = lrow[i] | nw[i];
             if (threadIdx.x == 0 && blockIdx.x == 0) {
                 topo[internal_node] = TopoNode{cur, leaf_node, int_row, 0u};
-                if (parent < 0) state[0] = internal_node;
-                else if (side) topo[parent].right = internal_node;
-                else topo[parent].left = internal_node;
+                state[0] = *root_out = parent < 0 ? internal_node : root;   // (state[0]: for the host)
+                if (parent >= 0) {
+                    if (side) topo[parent].right = internal_node;
+                    else topo[parent].left = internal_node;
+                }
             }
             return;
         } else {
@@ -2963,10 +3010,9 @@ __global__ void __launch_bounds__(1024) k_greedy_insert(uint64_t *bits, uint64_t
         }
     }
 }
-void launch_greedy_insert(uint64_t *bits, uint64_t n_words, TopoNode *topo, int *state, unsigned int *bar, unsigned long long *partials,
-                          int leaf_node, int internal_node, uint32_t new_row, uint32_t int_row, int blocks, hipStream_t st) {
-    hipLaunchKernelGGL(k_greedy_insert, dim3(blocks), dim3(1024), 0, st, bits, n_words, topo, state, bar, partials, leaf_node, internal_node,
-                       new_row, int_row);
+void launch_greedy_insert(uint64_t *bits, uint64_t n_words, TopoNode *topo, int *state, unsigned long long *sync, int leaf_node, int internal_node,
+                          uint32_t new_row, uint32_t int_row, uint32_t seq, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_greedy_insert, dim3(blocks), dim3(1024), 0, st, bits, n_words, topo, state, sync, leaf_node, internal_node, new_row, int_row, seq);
 }
 
 // Internal filter = OR of its children (node_union, bloom_tree.rs:238-239 / bloom_filter.rs:275-278).
