@@ -109,12 +109,13 @@ __device__ __forceinline__ void stage_window(BlockLds &lds, uint32_t wave, const
 // ---- rustc-hash 2.1 ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t fx_mm(uint64_t x, uint64_t y) { return (x * y) ^ __umul64hi(x, y); }
 
-// hash_bytes over n bytes at byte address `a` of LDS word array `w` (n is wave-uniform).
-__device__ __forceinline__ uint64_t fx_hash_bytes_lds(const uint32_t *w, uint32_t a, uint32_t n) {
+// hash_bytes over n bytes at byte address `a` of LDS word array `w` (n is wave-uniform); `first8` = the first eight of
+// them (the caller has read them for the canonical choice; ignored when n < 8).
+__device__ __forceinline__ uint64_t fx_hash_bytes_lds(const uint32_t *w, uint32_t a, uint32_t n, uint64_t first8) {
     uint64_t s0 = FX_SEED1, s1 = FX_SEED2;
     if (n <= 16) {
         if (n >= 8) {
-            s0 ^= lds_u64(w, a);
+            s0 ^= first8;
             s1 ^= lds_u64(w, a + n - 8);
         } else if (n >= 4) {
             s0 ^= lds_u32(w, a);
@@ -125,14 +126,17 @@ __device__ __forceinline__ uint64_t fx_hash_bytes_lds(const uint32_t *w, uint32_
             s1 ^= (hi << 8) | mid;
         }
     } else {
+        uint64_t x = first8;
         uint32_t off = 0;
-        while (off < n - 16) {
-            uint64_t x = lds_u64(w, a + off), y = lds_u64(w, a + off + 8);
+        do {
+            const uint64_t y = lds_u64(w, a + off + 8);
             uint64_t t = fx_mm(s0 ^ x, FX_PTZC ^ y);
             s0 = s1;
             s1 = t;
             off += 16;
-        }
+            if (off >= n - 16) break;
+            x = lds_u64(w, a + off);
+        } while (true);
         s0 ^= lds_u64(w, a + n - 16);
         s1 ^= lds_u64(w, a + n - 8);
     }
@@ -149,21 +153,33 @@ __device__ __forceinline__ void kmer_hashes_at(const uint32_t *fw, const uint32_
                                                const HashParams &hp, uint64_t &h1, uint64_t &h2) {
     const uint32_t k = hp.k;
     if (!valid) { fa = WIN_PAD; ra = WIN_PAD; }
-    // bytewise lexicographic compare == compare of byte-swapped dwords, first difference decides
+    // bytewise lexicographic compare == compare of the byte-swapped words, first difference decides.  The first eight bytes
+    // decide nearly always (and the chosen strand's eight are the first word of the hash); the loop is for what is left.
     bool use_rc = false, decided = !valid;
-    for (uint32_t j = 0; j < k; j += 4) {
-        uint32_t f = lds_u32(fw, fa + j), r = lds_u32(rw, ra + j);
-        uint32_t rem = k - j;
-        if (rem < 4) { uint32_t m = (1u << (8u * rem)) - 1u; f &= m; r &= m; }
-        if (!decided && f != r) {
-            use_rc = __builtin_bswap32(r) < __builtin_bswap32(f);
-            decided = true;
+    uint64_t f8 = 0, r8 = 0;
+    uint32_t j0 = 0;
+    if (k >= 8) {  // (wave-uniform)
+        f8 = lds_u64(fw, fa);
+        r8 = lds_u64(rw, ra);
+        use_rc = valid && __builtin_bswap64(r8) < __builtin_bswap64(f8);
+        decided = decided || f8 != r8;
+        j0 = 8;
+    }
+    if (ballot64(!decided) != 0) {
+        for (uint32_t j = j0; j < k; j += 4) {
+            uint32_t f = lds_u32(fw, fa + j), r = lds_u32(rw, ra + j);
+            uint32_t rem = k - j;
+            if (rem < 4) { uint32_t m = (1u << (8u * rem)) - 1u; f &= m; r &= m; }
+            if (!decided && f != r) {
+                use_rc = __builtin_bswap32(r) < __builtin_bswap32(f);
+                decided = true;
+            }
+            if (ballot64(!decided) == 0) break;
         }
-        if (ballot64(!decided) == 0) break;
     }
     const uint32_t *cw = use_rc ? rw : fw;
     uint32_t ca = use_rc ? ra : fa;
-    const uint64_t hbk = fx_hash_bytes_lds(cw, ca, k) * FX_K;
+    const uint64_t hbk = fx_hash_bytes_lds(cw, ca, k, use_rc ? r8 : f8) * FX_K;
     h1 = rotl64(hp.a1 + hbk, 26);
     h2 = rotl64(hp.a2 + hbk, 26);
 }
@@ -265,13 +281,17 @@ __device__ __forceinline__ uint4 make_probe_record(uint64_t h1, uint64_t h2, con
     rec.y = mod_nbits30(h2, hp);
     uint64_t r = (h1 + 2) * h2;
     rec.z = mod_nbits30(r, hp);
-    uint32_t cm = 0;
-    for (uint32_t i = 3; i < hp.num_hashes; ++i) {
-        uint64_t rn = r + h2;
-        cm |= (rn < r ? 1u : 0u) << (i - 3);
-        r = rn;
-    }
-    rec.w = cm;
+    // the walk r += h2 with the carry-out of every step shifted into cm (add, add-with-carry, cm = 2 cm + carry: three
+    // instructions a step; compare-and-select code was seven); the first step ends up in the highest of the n bits
+    uint32_t rl = (uint32_t)r, rh = (uint32_t)(r >> 32), cm = 0;
+    const uint32_t hl = (uint32_t)h2, hh = (uint32_t)(h2 >> 32);
+    const uint32_t n = hp.num_hashes > 3 ? hp.num_hashes - 3 : 0;
+    for (uint32_t i = 0; i < n; ++i)
+        asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, %2, %2, vcc"
+            : "+v"(rl), "+v"(rh), "+v"(cm)
+            : "v"(hl), "v"(hh)
+            : "vcc");
+    rec.w = n ? __brev(cm) >> (32u - n) : 0u;
     return rec;
 }
 struct RecordIter {
