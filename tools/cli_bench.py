@@ -18,7 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-CLI = os.path.join(ROOT, "phagefilter_amd", "phage_filter")
+CLI = os.environ.get("PFQ_CLI_BIN") or os.path.join(ROOT, "phagefilter_amd", "phage_filter")   # (PFQ_CLI_BIN: A/B of two builds)
 
 
 def write_fastq(path, reads_np, first_id):
